@@ -1,0 +1,266 @@
+"""ctypes binding of the CPU oracle (oracle/orb_oracle.h).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  The product package (orbslam3_cpp_fork_amd) never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "liborb_oracle.so")
+
+KP_DTYPE = np.dtype(
+    [("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")]
+)
+assert KP_DTYPE.itemsize == 28
+
+
+def build(force=False):
+    """Compile the oracle with g++ (oracle/Makefile)."""
+    if force or not os.path.exists(_SO):
+        subprocess.check_call(["make", "-C", _HERE] + (["-B"] if force else []), stdout=subprocess.DEVNULL)
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_SO)
+        u8p, i32p, f32p = C.POINTER(C.c_uint8), C.POINTER(C.c_int), C.POINTER(C.c_float)
+        L.orao_create.restype = C.c_void_p
+        L.orao_create.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]
+        L.orao_destroy.argtypes = [C.c_void_p]
+        L.orao_extract.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, i32p]
+        L.orao_get_levels.argtypes = [C.c_void_p]
+        L.orao_get_scale_tables.argtypes = [C.c_void_p] + [C.c_void_p] * 4
+        L.orao_get_features_per_level.argtypes = [C.c_void_p, C.c_void_p]
+        L.orao_get_umax.argtypes = [C.c_void_p, C.c_void_p]
+        for f in (L.orao_pyramid_level, L.orao_blurred_level):
+            f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, i32p, i32p]
+        L.orao_level_candidates.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.orao_level_keypoints.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.orao_resize_linear_8u.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_int, C.c_int, C.c_size_t]
+        L.orao_gaussian_blur7_8u.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_size_t]
+        L.orao_fast9_16.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.orao_fast_atan2.restype = C.c_float
+        L.orao_fast_atan2.argtypes = [C.c_float, C.c_float]
+        L.orao_cv_round_f.argtypes = [C.c_float]
+        L.orao_ic_angle.restype = C.c_float
+        L.orao_ic_angle.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int]
+        L.orao_orb_descriptor.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_float, C.c_void_p]
+        L.orao_distribute_octtree.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int] + [C.c_int] * 5 + [C.c_void_p, C.c_int]
+        L.orao_libm_sincos_deg.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.orao_sincos_port_mismatches.restype = C.c_long
+        L.orao_sincos_port_mismatches.argtypes = [C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_void_p, i32p]
+        L.orao_hamming.argtypes = [C.c_void_p, C.c_void_p]
+        L.orao_three_maxima.argtypes = [C.c_void_p, C.c_int, i32p, i32p, i32p]
+        L.orao_match_groups.argtypes = (
+            [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 8 + [C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p]
+        )
+        L.orao_match_window.argtypes = (
+            [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+            + [C.c_float] * 4
+            + [C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]
+        )
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _u8img(img):
+    img = np.asarray(img)
+    assert img.dtype == np.uint8 and img.ndim == 2
+    if img.strides[1] != 1:
+        img = np.ascontiguousarray(img)
+    return img
+
+
+class OracleExtractor:
+    """Mirror of ORB_SLAM3::ORBextractor (include/ORBextractor.h:41-119) over the CPU oracle."""
+
+    def __init__(self, nfeatures=1000, scale_factor=1.2, nlevels=8, ini_th_fast=20, min_th_fast=7):
+        self._h = lib().orao_create(nfeatures, scale_factor, nlevels, ini_th_fast, min_th_fast)
+        if not self._h:
+            raise ValueError("bad extractor parameters")
+        self.nfeatures, self.nlevels = nfeatures, nlevels
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orao_destroy(self._h)
+            self._h = None
+
+    def __call__(self, image, lapping=(0, 0), cap=None):
+        """Returns (mono_index, keypoints[KP_DTYPE], descriptors[n,32] u8)."""
+        if image is None or image.size == 0:
+            return -1, np.zeros(0, KP_DTYPE), np.zeros((0, 32), np.uint8)
+        img = _u8img(image)
+        cap = cap or (self.nfeatures + 8 * self.nlevels + 64) * 2
+        kps = np.zeros(cap, KP_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        n = C.c_int(0)
+        rc = lib().orao_extract(self._h, _p(img), img.shape[0], img.shape[1], img.strides[0], lapping[0], lapping[1], _p(kps), _p(desc), cap, C.byref(n))
+        return rc, kps[: n.value].copy(), desc[: n.value].copy()
+
+    def scale_tables(self):
+        t = [np.zeros(self.nlevels, np.float32) for _ in range(4)]
+        lib().orao_get_scale_tables(self._h, *[_p(a) for a in t])
+        return t
+
+    def features_per_level(self):
+        a = np.zeros(self.nlevels, np.int32)
+        lib().orao_get_features_per_level(self._h, _p(a))
+        return a
+
+    def umax(self):
+        a = np.zeros(16, np.int32)
+        lib().orao_get_umax(self._h, _p(a))
+        return a
+
+    def _level(self, fn, level):
+        r, c = C.c_int(0), C.c_int(0)
+        if fn(self._h, level, None, 0, C.byref(r), C.byref(c)) != 0:
+            raise IndexError(level)
+        out = np.zeros((r.value, c.value), np.uint8)
+        fn(self._h, level, _p(out), out.strides[0], C.byref(r), C.byref(c))
+        return out
+
+    def pyramid_level(self, level):
+        return self._level(lib().orao_pyramid_level, level)
+
+    def blurred_level(self, level):
+        return self._level(lib().orao_blurred_level, level)
+
+    def level_candidates(self, level, cap=1 << 20):
+        xs, ys, rs = (np.zeros(cap, np.int32) for _ in range(3))
+        n = lib().orao_level_candidates(self._h, level, _p(xs), _p(ys), _p(rs), cap)
+        return xs[:n].copy(), ys[:n].copy(), rs[:n].copy()
+
+    def level_keypoints(self, level, cap=1 << 16):
+        out = np.zeros(cap, KP_DTYPE)
+        n = lib().orao_level_keypoints(self._h, level, _p(out), cap)
+        return out[:n].copy()
+
+
+def resize_linear(src, dw, dh):
+    src = _u8img(src)
+    dst = np.zeros((dh, dw), np.uint8)
+    lib().orao_resize_linear_8u(_p(src), src.shape[1], src.shape[0], src.strides[0], _p(dst), dw, dh, dst.strides[0])
+    return dst
+
+
+def gaussian_blur7(src):
+    src = _u8img(src)
+    dst = np.zeros_like(src)
+    lib().orao_gaussian_blur7_8u(_p(src), src.shape[1], src.shape[0], src.strides[0], _p(dst), dst.strides[0])
+    return dst
+
+
+def fast9_16(img, threshold, cap=1 << 20):
+    img = _u8img(img)
+    xs, ys, sc = (np.zeros(cap, np.int32) for _ in range(3))
+    n = lib().orao_fast9_16(_p(img), img.shape[1], img.shape[0], img.strides[0], threshold, _p(xs), _p(ys), _p(sc), cap)
+    return xs[:n].copy(), ys[:n].copy(), sc[:n].copy()
+
+
+def fast_atan2(y, x):
+    return lib().orao_fast_atan2(float(y), float(x))
+
+
+def cv_round(v):
+    return lib().orao_cv_round_f(float(v))
+
+
+def ic_angle(img, x, y):
+    img = _u8img(img)
+    return lib().orao_ic_angle(_p(img), img.strides[0], x, y)
+
+
+def orb_descriptor(blurred, x, y, angle_deg):
+    img = _u8img(blurred)
+    d = np.zeros(32, np.uint8)
+    lib().orao_orb_descriptor(_p(img), img.strides[0], x, y, float(angle_deg), _p(d))
+    return d
+
+
+def distribute_octtree(xs, ys, resp, min_x, max_x, min_y, max_y, n_target):
+    xs = np.ascontiguousarray(xs, np.float32)
+    ys = np.ascontiguousarray(ys, np.float32)
+    resp = np.ascontiguousarray(resp, np.float32)
+    cap = len(xs) + 8
+    out = np.zeros(cap, np.int32)
+    n = lib().orao_distribute_octtree(_p(xs), _p(ys), _p(resp), len(xs), min_x, max_x, min_y, max_y, n_target, _p(out), cap)
+    if n < 0:
+        return n, None
+    return n, out[:n].copy()
+
+
+def libm_sincos_deg(deg):
+    deg = np.ascontiguousarray(deg, np.float32)
+    c, s = np.zeros_like(deg), np.zeros_like(deg)
+    lib().orao_libm_sincos_deg(_p(deg), len(deg), _p(c), _p(s))
+    return c, s
+
+
+def sincos_port_mismatches(bits_lo, bits_hi, fma_variant=0, nthreads=8):
+    bad = np.zeros(16, np.uint32)
+    nb = C.c_int(0)
+    n = lib().orao_sincos_port_mismatches(bits_lo, bits_hi, fma_variant, nthreads, _p(bad), C.byref(nb))
+    return n, bad[: nb.value]
+
+
+def hamming(a, b):
+    a = np.ascontiguousarray(a, np.uint8)
+    b = np.ascontiguousarray(b, np.uint8)
+    return lib().orao_hamming(_p(a), _p(b))
+
+
+def three_maxima(counts):
+    counts = np.ascontiguousarray(counts, np.int32)
+    i1, i2, i3 = C.c_int(-1), C.c_int(-1), C.c_int(-1)
+    lib().orao_three_maxima(_p(counts), len(counts), C.byref(i1), C.byref(i2), C.byref(i3))
+    return i1.value, i2.value, i3.value
+
+
+def _opt(a, dt):
+    return None if a is None else np.ascontiguousarray(a, dt)
+
+
+def match_groups(q, t, q_angle=None, t_angle=None, th=50, ratio=0.7, strict_lt=False, check_ori=True, groups=None, q_valid=None, t_valid=None):
+    """groups = None (brute force) or (q_off, q_idx, t_off, t_idx)."""
+    q = np.ascontiguousarray(q, np.uint8)
+    t = np.ascontiguousarray(t, np.uint8)
+    nq, nt = len(q), len(t)
+    if groups is None:
+        ng, qo, qi, to, ti = 1, None, None, None, None
+    else:
+        qo, qi, to, ti = (np.ascontiguousarray(a, np.int32) for a in groups)
+        ng = len(qo) - 1
+    qa = _opt(q_angle if q_angle is not None else np.zeros(nq), np.float32)
+    ta = _opt(t_angle if t_angle is not None else np.zeros(nt), np.float32)
+    qv, tv = _opt(q_valid, np.uint8), _opt(t_valid, np.uint8)
+    mq, mt = np.zeros(nq, np.int32), np.zeros(nt, np.int32)
+    n = lib().orao_match_groups(
+        _p(q), nq, _p(t), nt, ng, _p(qo), _p(qi), _p(to), _p(ti), _p(qv), _p(tv), _p(qa), _p(ta), th, int(strict_lt), ratio, int(check_ori), _p(mq), _p(mt)
+    )
+    return n, mq, mt
+
+
+def match_window(d1, kp1, d2, kp2, prev_matched, bounds, window=100, th=50, ratio=0.9, check_ori=True):
+    d1 = np.ascontiguousarray(d1, np.uint8)
+    d2 = np.ascontiguousarray(d2, np.uint8)
+    kp1 = np.ascontiguousarray(kp1, KP_DTYPE)
+    kp2 = np.ascontiguousarray(kp2, KP_DTYPE)
+    pm = np.ascontiguousarray(prev_matched, np.float32).copy()
+    m12 = np.zeros(len(kp1), np.int32)
+    n = lib().orao_match_window(_p(d1), _p(kp1), len(kp1), _p(d2), _p(kp2), len(kp2), _p(pm), *[float(b) for b in bounds], window, th, ratio, int(check_ori), _p(m12))
+    return n, m12, pm

@@ -1,0 +1,1072 @@
+// orb_oracle.cpp -- CPU ORACLE (test infrastructure; see orb_oracle.h for status: "parity unpinned").
+//
+// A single-threaded restatement of the reference hot path.  Every function cites the reference
+// (or OpenCV 4.5.x) code it follows.  Build: g++ -O3 -march=native -ffp-contract=off (oracle/Makefile);
+// contraction is off so that float expressions evaluate as written.
+#include "orb_oracle.h"
+
+#include <algorithm>
+#include <atomic>
+#include <climits>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <list>
+#include <thread>
+#include <utility>
+#include <vector>
+
+#include "../orbslam3_cpp_fork_amd/csrc/orb_sincosf_port.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// constants (src/ORBextractor.cc:62-64)
+// ------------------------------------------------------------------------------------------------
+const int PATCH_SIZE      = 31;
+const int HALF_PATCH_SIZE = 15;
+const int EDGE_THRESHOLD  = 19;
+
+// rBRIEF pattern data (src/ORBextractor.cc:141-398)
+const signed char kPattern[1024] = {
+#include "../orbslam3_cpp_fork_amd/csrc/orb_pattern.inc"
+};
+
+// cvRound: round half to even (OpenCV fast_math.hpp; SSE cvtss2si / lrint).
+inline int cvRoundF(float v) { return (int)lrintf(v); }
+inline int cvRoundD(double v) { return (int)lrint(v); }
+inline int cvFloorF(float v) {
+  int i = (int)v;
+  return i - (i > v);
+}
+
+struct Img {
+  int                  w = 0, h = 0;
+  std::vector<uint8_t> d;
+  void                 alloc(int w_, int h_) {
+    w = w_;
+    h = h_;
+    d.assign((size_t)w * h, 0);
+  }
+  uint8_t*       row(int y) { return d.data() + (size_t)y * w; }
+  const uint8_t* row(int y) const { return d.data() + (size_t)y * w; }
+};
+
+// ------------------------------------------------------------------------------------------------
+// cv::resize(INTER_LINEAR) for CV_8UC1, non-IPP (OpenCV 4.5.x modules/imgproc/src/resize.cpp:
+// resize() table set-up, HResizeLinear<uchar,int,short,2048>, VResizeLinear fixed-point cast).
+// ------------------------------------------------------------------------------------------------
+void resizeLinear8u(const uint8_t* src, int sw, int sh, size_t sstep, uint8_t* dst, int dw, int dh, size_t dstep) {
+  const double inv_scale_x = (double)dw / sw, inv_scale_y = (double)dh / sh;
+  const double scale_x = 1. / inv_scale_x, scale_y = 1. / inv_scale_y;
+  std::vector<int>   xofs(dw), yofs(dh);
+  std::vector<short> ialpha(2 * (size_t)dw), ibeta(2 * (size_t)dh);
+  for (int dx = 0; dx < dw; dx++) {
+    float fx = (float)((dx + 0.5) * scale_x - 0.5);
+    int   sx = cvFloorF(fx);
+    fx -= sx;
+    if (sx < 0) {
+      fx = 0;
+      sx = 0;
+    }
+    if (sx >= sw - 1) {
+      fx = 0;
+      sx = sw - 1;
+    }
+    xofs[dx]           = sx;
+    ialpha[2 * dx]     = (short)std::min(std::max(cvRoundF((1.f - fx) * 2048), SHRT_MIN), SHRT_MAX);
+    ialpha[2 * dx + 1] = (short)std::min(std::max(cvRoundF(fx * 2048), SHRT_MIN), SHRT_MAX);
+  }
+  for (int dy = 0; dy < dh; dy++) {
+    float fy = (float)((dy + 0.5) * scale_y - 0.5);
+    int   sy = cvFloorF(fy);
+    fy -= sy;
+    yofs[dy]          = sy;
+    ibeta[2 * dy]     = (short)std::min(std::max(cvRoundF((1.f - fy) * 2048), SHRT_MIN), SHRT_MAX);
+    ibeta[2 * dy + 1] = (short)std::min(std::max(cvRoundF(fy * 2048), SHRT_MIN), SHRT_MAX);
+  }
+  std::vector<int> rows[2];
+  rows[0].resize(dw);
+  rows[1].resize(dw);
+  for (int dy = 0; dy < dh; dy++) {
+    for (int k = 0; k < 2; k++) {
+      int sy = std::min(std::max(yofs[dy] + k, 0), sh - 1);  // clip(sy0 - ksize2 + 1 + k, 0, ssize.height)
+      const uint8_t* S = src + (size_t)sy * sstep;
+      int*           D = rows[k].data();
+      for (int dx = 0; dx < dw; dx++) {
+        int sx  = xofs[dx];
+        int sx1 = std::min(sx + 1, sw - 1);  // for dx >= xmax the second tap has weight 0
+        D[dx]   = S[sx] * ialpha[2 * dx] + S[sx1] * ialpha[2 * dx + 1];
+      }
+    }
+    const int  b0 = ibeta[2 * dy], b1 = ibeta[2 * dy + 1];
+    const int *S0 = rows[0].data(), *S1 = rows[1].data();
+    uint8_t*   D  = dst + (size_t)dy * dstep;
+    for (int x = 0; x < dw; x++) D[x] = (uint8_t)((((b0 * (S0[x] >> 4)) >> 16) + ((b1 * (S1[x] >> 4)) >> 16) + 2) >> 2);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// cv::GaussianBlur(8U, Size(7,7), 2, 2, BORDER_REFLECT_101): bit-exact fixed-point path
+// (OpenCV 4.5.x smooth.dispatch.cpp getGaussianKernelFixedPoint_ED -> Q8 taps summing to 256;
+// smooth.simd.hpp fixedSmoothInvoker: horizontal u8*Q8.8 -> u16, vertical Q8.8*Q8.8 -> Q16.16,
+// rounded by (v + 32768) >> 16).
+// ------------------------------------------------------------------------------------------------
+const int kGauss7[7] = {18, 34, 48, 56, 48, 34, 18};  // version-sensitive constant
+
+inline int reflect101(int p, int n) {
+  if (n == 1) return 0;
+  while (p < 0 || p >= n) {
+    if (p < 0)
+      p = -p;
+    else
+      p = 2 * n - 2 - p;
+  }
+  return p;
+}
+
+void gaussianBlur7(const uint8_t* src, int w, int h, size_t sstep, uint8_t* dst, size_t dstep) {
+  std::vector<uint16_t> hbuf((size_t)w * h);
+  std::vector<uint8_t>  prow((size_t)w + 6);
+  for (int y = 0; y < h; y++) {
+    const uint8_t* S = src + (size_t)y * sstep;
+    for (int x = -3; x < w + 3; x++) prow[x + 3] = S[reflect101(x, w)];
+    uint16_t*      H = hbuf.data() + (size_t)y * w;
+    const uint8_t* P = prow.data();
+    for (int x = 0; x < w; x++) {
+      unsigned acc = kGauss7[0] * (P[x] + P[x + 6]) + kGauss7[1] * (P[x + 1] + P[x + 5]) + kGauss7[2] * (P[x + 2] + P[x + 4]) +
+                     kGauss7[3] * P[x + 3];
+      H[x] = (uint16_t)acc;  // <= 255 * 256, no saturation possible
+    }
+  }
+  for (int y = 0; y < h; y++) {
+    const uint16_t* R[7];
+    for (int k = 0; k < 7; k++) R[k] = hbuf.data() + (size_t)reflect101(y + k - 3, h) * w;
+    uint8_t* D = dst + (size_t)y * dstep;
+    for (int x = 0; x < w; x++) {
+      uint32_t acc = (uint32_t)kGauss7[0] * ((uint32_t)R[0][x] + R[6][x]) + (uint32_t)kGauss7[1] * ((uint32_t)R[1][x] + R[5][x]) +
+                     (uint32_t)kGauss7[2] * ((uint32_t)R[2][x] + R[4][x]) + (uint32_t)kGauss7[3] * R[3][x];
+      D[x] = (uint8_t)((acc + 32768u) >> 16);  // <= 255
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// cv::FAST(img, kps, threshold, true) type 9_16 (OpenCV features2d/src/fast.cpp FAST_t<16>,
+// fast_score.cpp cornerScore<16>).  Emission order: row-major.
+// ------------------------------------------------------------------------------------------------
+const int kCircle[16][2] = {{0, 3},  {1, 3},   {2, 2},   {3, 1},   {3, 0},  {3, -1}, {2, -2}, {1, -3},
+                            {0, -3}, {-1, -3}, {-2, -2}, {-3, -1}, {-3, 0}, {-3, 1}, {-2, 2}, {-1, 3}};
+
+struct FastPt {
+  int x, y, score;
+};
+
+inline int cornerScore16(const uint8_t* ptr, const int* pixel, int threshold) {
+  const int K = 8, N = K * 3 + 1;
+  int       k, v = ptr[0];
+  short     d[N];
+  for (k = 0; k < N; k++) d[k] = (short)(v - ptr[pixel[k]]);
+  int a0 = threshold;
+  for (k = 0; k < 16; k += 2) {
+    int a = std::min((int)d[k + 1], (int)d[k + 2]);
+    a     = std::min(a, (int)d[k + 3]);
+    if (a <= a0) continue;
+    a  = std::min(a, (int)d[k + 4]);
+    a  = std::min(a, (int)d[k + 5]);
+    a  = std::min(a, (int)d[k + 6]);
+    a  = std::min(a, (int)d[k + 7]);
+    a  = std::min(a, (int)d[k + 8]);
+    a0 = std::max(a0, std::min(a, (int)d[k]));
+    a0 = std::max(a0, std::min(a, (int)d[k + 9]));
+  }
+  int b0 = -a0;
+  for (k = 0; k < 16; k += 2) {
+    int b = std::max((int)d[k + 1], (int)d[k + 2]);
+    b     = std::max(b, (int)d[k + 3]);
+    b     = std::max(b, (int)d[k + 4]);
+    b     = std::max(b, (int)d[k + 5]);
+    if (b >= b0) continue;
+    b  = std::max(b, (int)d[k + 6]);
+    b  = std::max(b, (int)d[k + 7]);
+    b  = std::max(b, (int)d[k + 8]);
+    b0 = std::min(b0, std::max(b, (int)d[k]));
+    b0 = std::min(b0, std::max(b, (int)d[k + 9]));
+  }
+  return -b0 - 1;
+}
+
+void fast9_16(const uint8_t* img, int cols, int rows, size_t step, int threshold, std::vector<FastPt>& out) {
+  out.clear();
+  if (rows < 7 || cols < 7) return;
+  threshold = std::min(std::max(threshold, 0), 255);
+  int pixel[25];
+  for (int k = 0; k < 16; k++) pixel[k] = kCircle[k][0] + kCircle[k][1] * (int)step;
+  for (int k = 16; k < 25; k++) pixel[k] = pixel[k - 16];
+  uint8_t threshold_tab[512];
+  for (int i = -255; i <= 255; i++) threshold_tab[i + 255] = (uint8_t)(i < -threshold ? 1 : i > threshold ? 2 : 0);
+  // three rolling rows of scores (uchar in OpenCV) + corner position lists
+  std::vector<uint8_t> sbuf[3];
+  std::vector<int>     cpos[3];
+  for (int i = 0; i < 3; i++) {
+    sbuf[i].assign(cols, 0);
+    cpos[i].clear();
+  }
+  for (int i = 3; i < rows - 2; i++) {
+    const uint8_t*        ptr  = img + (size_t)i * step;
+    std::vector<uint8_t>& curr = sbuf[(i - 3) % 3];
+    std::vector<int>&     cp   = cpos[(i - 3) % 3];
+    std::fill(curr.begin(), curr.end(), 0);
+    cp.clear();
+    if (i < rows - 3) {
+      for (int j = 3; j < cols - 3; j++) {
+        const uint8_t* p   = ptr + j;
+        int            v   = p[0];
+        const uint8_t* tab = &threshold_tab[0] - v + 255;
+        // quick rejection exactly as FAST_t<16>: a 9-arc must contain one pixel of every opposite pair
+        int d = tab[p[pixel[0]]] | tab[p[pixel[8]]];
+        if (d == 0) continue;
+        d &= tab[p[pixel[2]]] | tab[p[pixel[10]]];
+        d &= tab[p[pixel[4]]] | tab[p[pixel[12]]];
+        d &= tab[p[pixel[6]]] | tab[p[pixel[14]]];
+        if (d == 0) continue;
+        d &= tab[p[pixel[1]]] | tab[p[pixel[9]]];
+        d &= tab[p[pixel[3]]] | tab[p[pixel[11]]];
+        d &= tab[p[pixel[5]]] | tab[p[pixel[13]]];
+        d &= tab[p[pixel[7]]] | tab[p[pixel[15]]];
+        bool corner = false;
+        if (d & 1) {  // darker arc: x < v - t
+          int vt = v - threshold, count = 0;
+          for (int k = 0; k < 25; k++) {
+            int x = p[pixel[k]];
+            if (x < vt) {
+              if (++count > 8) {
+                corner = true;
+                break;
+              }
+            } else
+              count = 0;
+          }
+        }
+        if (!corner && (d & 2)) {  // brighter arc: x > v + t
+          int vt = v + threshold, count = 0;
+          for (int k = 0; k < 25; k++) {
+            int x = p[pixel[k]];
+            if (x > vt) {
+              if (++count > 8) {
+                corner = true;
+                break;
+              }
+            } else
+              count = 0;
+          }
+        }
+        if (corner) {
+          cp.push_back(j);
+          curr[j] = (uint8_t)cornerScore16(p, pixel, threshold);
+        }
+      }
+    }
+    if (i == 3) continue;
+    const std::vector<uint8_t>& prev  = sbuf[(i - 4 + 3) % 3];
+    const std::vector<uint8_t>& pprev = sbuf[(i - 5 + 3) % 3];
+    const std::vector<int>&     pc    = cpos[(i - 4 + 3) % 3];
+    for (size_t k = 0; k < pc.size(); k++) {
+      int j     = pc[k];
+      int score = prev[j];
+      if (score > prev[j + 1] && score > prev[j - 1] && score > pprev[j - 1] && score > pprev[j] && score > pprev[j + 1] &&
+          score > curr[j - 1] && score > curr[j] && score > curr[j + 1]) {
+        out.push_back({j, i - 1, score});
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// cv::fastAtan2 scalar path (OpenCV core/src/mathfuncs_core.simd.hpp / mathfuncs.cpp)
+// ------------------------------------------------------------------------------------------------
+float fastAtan2(float y, float x) {
+  static const float p1 = 0.9997878412794807f * (float)(180 / 3.14159265358979323846);
+  static const float p3 = -0.3258083974640975f * (float)(180 / 3.14159265358979323846);
+  static const float p5 = 0.1555786518463281f * (float)(180 / 3.14159265358979323846);
+  static const float p7 = -0.04432655554792128f * (float)(180 / 3.14159265358979323846);
+  const float        eps = (float)2.2204460492503131e-16;
+  float              ax = std::abs(x), ay = std::abs(y);
+  float              a, c, c2;
+  if (ax >= ay) {
+    c  = ay / (ax + eps);
+    c2 = c * c;
+    a  = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+  } else {
+    c  = ax / (ay + eps);
+    c2 = c * c;
+    a  = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+  }
+  if (x < 0) a = 180.f - a;
+  if (y < 0) a = 360.f - a;
+  return a;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Reference data model
+// ------------------------------------------------------------------------------------------------
+struct KP {  // cv::KeyPoint + bookkeeping index `src` (position in the candidate feed)
+  float x = 0, y = 0, size = 7, angle = -1, response = 0;
+  int   octave = 0, class_id = -1;
+  int   src = -1;
+};
+
+// IC_Angle (src/ORBextractor.cc:66-91)
+float icAngle(const uint8_t* img, size_t step, int px, int py, const int* u_max) {
+  int            m_01 = 0, m_10 = 0;
+  const uint8_t* center = img + (size_t)py * step + px;
+  for (int u = -HALF_PATCH_SIZE; u <= HALF_PATCH_SIZE; ++u) m_10 += u * center[u];
+  int istep = (int)step;
+  for (int v = 1; v <= HALF_PATCH_SIZE; ++v) {
+    int v_sum = 0;
+    int d     = u_max[v];
+    for (int u = -d; u <= d; ++u) {
+      int val_plus = center[u + v * istep], val_minus = center[u - v * istep];
+      v_sum += (val_plus - val_minus);
+      m_10 += u * (val_plus + val_minus);
+    }
+    m_01 += v * v_sum;
+  }
+  return fastAtan2((float)m_01, (float)m_10);
+}
+
+// computeOrbDescriptor (src/ORBextractor.cc:93-139)
+const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
+
+void orbDescriptor(const uint8_t* img, size_t step, int cx, int cy, float angle_deg, uint8_t* desc) {
+  float          angle  = angle_deg * factorPI;
+  float          a = (float)std::cos(angle), b = (float)std::sin(angle);  // libm cosf / sinf
+  const uint8_t* center = img + (size_t)cy * step + cx;
+  const int      istep  = (int)step;
+  const signed char* pat = kPattern;
+  for (int i = 0; i < 32; ++i, pat += 32) {
+    int val = 0;
+    for (int k = 0; k < 8; k++) {
+      int x0 = pat[4 * k + 0], y0 = pat[4 * k + 1], x1 = pat[4 * k + 2], y1 = pat[4 * k + 3];
+      int t0 = center[cvRoundF(x0 * b + y0 * a) * istep + cvRoundF(x0 * a - y0 * b)];
+      int t1 = center[cvRoundF(x1 * b + y1 * a) * istep + cvRoundF(x1 * a - y1 * b)];
+      val |= (t0 < t1) << k;
+    }
+    desc[i] = (uint8_t)val;
+  }
+}
+
+// ExtractorNode (include/ORBextractor.h:28-39, src/ORBextractor.cc:481-540)
+struct Node {
+  int                       ULx = 0, ULy = 0, URx = 0, URy = 0, BLx = 0, BLy = 0, BRx = 0, BRy = 0;
+  std::vector<KP>           vKeys;
+  std::list<Node>::iterator lit;
+  bool                      bNoMore = false;
+
+  void DivideNode(Node& n1, Node& n2, Node& n3, Node& n4) const {
+    const int halfX = (int)std::ceil(static_cast<float>(URx - ULx) / 2);
+    const int halfY = (int)std::ceil(static_cast<float>(BRy - ULy) / 2);
+    n1.ULx = ULx, n1.ULy = ULy;
+    n1.URx = ULx + halfX, n1.URy = ULy;
+    n1.BLx = ULx, n1.BLy = ULy + halfY;
+    n1.BRx = ULx + halfX, n1.BRy = ULy + halfY;
+    n1.vKeys.reserve(vKeys.size());
+    n2.ULx = n1.URx, n2.ULy = n1.URy;
+    n2.URx = URx, n2.URy = URy;
+    n2.BLx = n1.BRx, n2.BLy = n1.BRy;
+    n2.BRx = URx, n2.BRy = ULy + halfY;
+    n2.vKeys.reserve(vKeys.size());
+    n3.ULx = n1.BLx, n3.ULy = n1.BLy;
+    n3.URx = n1.BRx, n3.URy = n1.BRy;
+    n3.BLx = BLx, n3.BLy = BLy;
+    n3.BRx = n1.BRx, n3.BRy = BLy;
+    n3.vKeys.reserve(vKeys.size());
+    n4.ULx = n3.URx, n4.ULy = n3.URy;
+    n4.URx = n2.BRx, n4.URy = n2.BRy;
+    n4.BLx = n3.BRx, n4.BLy = n3.BRy;
+    n4.BRx = BRx, n4.BRy = BRy;
+    n4.vKeys.reserve(vKeys.size());
+    for (size_t i = 0; i < vKeys.size(); i++) {
+      const KP& kp = vKeys[i];
+      if (kp.x < n1.URx) {
+        if (kp.y < n1.BRy)
+          n1.vKeys.push_back(kp);
+        else
+          n3.vKeys.push_back(kp);
+      } else if (kp.y < n1.BRy)
+        n2.vKeys.push_back(kp);
+      else
+        n4.vKeys.push_back(kp);
+    }
+    if (n1.vKeys.size() == 1) n1.bNoMore = true;
+    if (n2.vKeys.size() == 1) n2.bNoMore = true;
+    if (n3.vKeys.size() == 1) n3.bNoMore = true;
+    if (n4.vKeys.size() == 1) n4.bNoMore = true;
+  }
+};
+
+// compareNodes (src/ORBextractor.cc:542-554)
+bool compareNodes(std::pair<int, Node*>& e1, std::pair<int, Node*>& e2) {
+  if (e1.first < e2.first) return true;
+  if (e1.first > e2.first) return false;
+  return e1.second->ULx < e2.second->ULx;
+}
+
+// DistributeOctTree (src/ORBextractor.cc:556-753).  Returns false on the nIni == 0 hazard (:568).
+bool distributeOctTree(const std::vector<KP>& vToDistributeKeys, int minX, int maxX, int minY, int maxY, int N,
+                       std::vector<KP>& vResultKeys) {
+  vResultKeys.clear();
+  const int nIni = (int)std::round(static_cast<float>(maxX - minX) / (maxY - minY));
+  if (nIni <= 0) return false;
+  const float hX = static_cast<float>(maxX - minX) / nIni;
+
+  std::list<Node>    lNodes;
+  std::vector<Node*> vpIniNodes(nIni);
+  for (int i = 0; i < nIni; i++) {
+    Node ni;
+    ni.ULx = (int)(hX * static_cast<float>(i)), ni.ULy = 0;      // cv::Point2i(float, int) truncates
+    ni.URx = (int)(hX * static_cast<float>(i + 1)), ni.URy = 0;
+    ni.BLx = ni.ULx, ni.BLy = maxY - minY;
+    ni.BRx = ni.URx, ni.BRy = maxY - minY;
+    ni.vKeys.reserve(vToDistributeKeys.size());
+    lNodes.push_back(ni);
+    vpIniNodes[i] = &lNodes.back();
+  }
+  for (size_t i = 0; i < vToDistributeKeys.size(); i++) {
+    const KP& kp = vToDistributeKeys[i];
+    vpIniNodes[(int)(kp.x / hX)]->vKeys.push_back(kp);
+  }
+  std::list<Node>::iterator lit = lNodes.begin();
+  while (lit != lNodes.end()) {
+    if (lit->vKeys.size() == 1) {
+      lit->bNoMore = true;
+      lit++;
+    } else if (lit->vKeys.empty())
+      lit = lNodes.erase(lit);
+    else
+      lit++;
+  }
+
+  bool                                bFinish = false;
+  std::vector<std::pair<int, Node*>> vSizeAndPointerToNode;
+  vSizeAndPointerToNode.reserve(lNodes.size() * 4);
+
+  auto pushChild = [&](Node& c, bool count, int& nToExpand) {
+    if (c.vKeys.size() > 0) {
+      lNodes.push_front(c);
+      if (c.vKeys.size() > 1) {
+        if (count) nToExpand++;
+        vSizeAndPointerToNode.push_back(std::make_pair((int)c.vKeys.size(), &lNodes.front()));
+        lNodes.front().lit = lNodes.begin();
+      }
+    }
+  };
+
+  while (!bFinish) {
+    int prevSize  = (int)lNodes.size();
+    lit           = lNodes.begin();
+    int nToExpand = 0;
+    vSizeAndPointerToNode.clear();
+    while (lit != lNodes.end()) {
+      if (lit->bNoMore) {
+        lit++;
+        continue;
+      } else {
+        Node n1, n2, n3, n4;
+        lit->DivideNode(n1, n2, n3, n4);
+        pushChild(n1, true, nToExpand);
+        pushChild(n2, true, nToExpand);
+        pushChild(n3, true, nToExpand);
+        pushChild(n4, true, nToExpand);
+        lit = lNodes.erase(lit);
+        continue;
+      }
+    }
+    if ((int)lNodes.size() >= N || (int)lNodes.size() == prevSize) {
+      bFinish = true;
+    } else if (((int)lNodes.size() + nToExpand * 3) > N) {
+      while (!bFinish) {
+        prevSize = (int)lNodes.size();
+        std::vector<std::pair<int, Node*>> vPrev = vSizeAndPointerToNode;
+        vSizeAndPointerToNode.clear();
+        std::sort(vPrev.begin(), vPrev.end(), compareNodes);  // libstdc++ introsort of this host
+        for (int j = (int)vPrev.size() - 1; j >= 0; j--) {
+          Node n1, n2, n3, n4;
+          vPrev[j].second->DivideNode(n1, n2, n3, n4);
+          int dummy = 0;
+          pushChild(n1, false, dummy);
+          pushChild(n2, false, dummy);
+          pushChild(n3, false, dummy);
+          pushChild(n4, false, dummy);
+          lNodes.erase(vPrev[j].second->lit);
+          if ((int)lNodes.size() >= N) break;
+        }
+        if ((int)lNodes.size() >= N || (int)lNodes.size() == prevSize) bFinish = true;
+      }
+    }
+  }
+  // keep the best point per node, first wins on ties (:735-750)
+  for (std::list<Node>::iterator it = lNodes.begin(); it != lNodes.end(); it++) {
+    std::vector<KP>& vNodeKeys   = it->vKeys;
+    KP*              pKP         = &vNodeKeys[0];
+    float            maxResponse = pKP->response;
+    for (size_t k = 1; k < vNodeKeys.size(); k++) {
+      if (vNodeKeys[k].response > maxResponse) {
+        pKP         = &vNodeKeys[k];
+        maxResponse = vNodeKeys[k].response;
+      }
+    }
+    vResultKeys.push_back(*pKP);
+  }
+  return true;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// ORBextractor (include/ORBextractor.h:41-119)
+// ------------------------------------------------------------------------------------------------
+struct orao_extractor {
+  int                nfeatures, nlevels, iniThFAST, minThFAST;
+  float              scaleFactor;
+  std::vector<float> mvScaleFactor, mvInvScaleFactor, mvLevelSigma2, mvInvLevelSigma2;
+  std::vector<int>   mnFeaturesPerLevel;
+  std::vector<int>   umax;
+  std::vector<Img>   pyramid, blurred;
+  std::vector<std::vector<KP>> candidates;  // per level, feed order (debug access)
+  std::vector<std::vector<KP>> levelKps;    // per level after octree + orientation
+
+  // src/ORBextractor.cc:403-465
+  orao_extractor(int nf, float sf, int nl, int ini, int mn) : nfeatures(nf), nlevels(nl), iniThFAST(ini), minThFAST(mn), scaleFactor(sf) {
+    mvScaleFactor.resize(nlevels);
+    mvLevelSigma2.resize(nlevels);
+    mvScaleFactor[0] = 1.0f;
+    mvLevelSigma2[0] = 1.0f;
+    for (int i = 1; i < nlevels; i++) {
+      mvScaleFactor[i] = mvScaleFactor[i - 1] * scaleFactor;
+      mvLevelSigma2[i] = mvScaleFactor[i] * mvScaleFactor[i];
+    }
+    mvInvScaleFactor.resize(nlevels);
+    mvInvLevelSigma2.resize(nlevels);
+    for (int i = 0; i < nlevels; i++) {
+      mvInvScaleFactor[i] = 1.0f / mvScaleFactor[i];
+      mvInvLevelSigma2[i] = 1.0f / mvLevelSigma2[i];
+    }
+    pyramid.resize(nlevels);
+    blurred.resize(nlevels);
+    mnFeaturesPerLevel.resize(nlevels);
+    float factor                   = 1.0f / scaleFactor;
+    float nDesiredFeaturesPerScale = nfeatures * (1 - factor) / (1 - (float)std::pow((double)factor, (double)nlevels));
+    int   sumFeatures              = 0;
+    for (int level = 0; level < nlevels - 1; level++) {
+      mnFeaturesPerLevel[level] = cvRoundF(nDesiredFeaturesPerScale);
+      sumFeatures += mnFeaturesPerLevel[level];
+      nDesiredFeaturesPerScale *= factor;
+    }
+    mnFeaturesPerLevel[nlevels - 1] = std::max(nfeatures - sumFeatures, 0);
+    umax.resize(HALF_PATCH_SIZE + 1);
+    int          v, v0, vmax = cvFloorF(HALF_PATCH_SIZE * std::sqrt(2.f) / 2 + 1);
+    int          vmin = (int)std::ceil(HALF_PATCH_SIZE * std::sqrt(2.f) / 2);
+    const double hp2  = HALF_PATCH_SIZE * HALF_PATCH_SIZE;
+    for (v = 0; v <= vmax; ++v) umax[v] = cvRoundD(std::sqrt(hp2 - v * v));
+    for (v = HALF_PATCH_SIZE, v0 = 0; v >= vmin; --v) {
+      while (umax[v0] == umax[v0 + 1]) ++v0;
+      umax[v] = v0;
+      ++v0;
+    }
+  }
+
+  // ComputePyramid (src/ORBextractor.cc:1140-1173).  The 19-px reflected border the reference adds
+  // around every level is never read by any consumer and is not materialised.
+  void computePyramid(const uint8_t* img, int rows, int cols, size_t step) {
+    for (int level = 0; level < nlevels; ++level) {
+      float scale = mvInvScaleFactor[level];
+      int   w = cvRoundF((float)cols * scale), h = cvRoundF((float)rows * scale);
+      pyramid[level].alloc(w, h);
+      if (level != 0) {
+        resizeLinear8u(pyramid[level - 1].d.data(), pyramid[level - 1].w, pyramid[level - 1].h, pyramid[level - 1].w,
+                       pyramid[level].d.data(), w, h, w);
+      } else {
+        for (int y = 0; y < rows; y++) memcpy(pyramid[0].row(y), img + (size_t)y * step, cols);
+      }
+    }
+  }
+
+  // ComputeKeyPointsOctTree (src/ORBextractor.cc:755-881)
+  bool computeKeyPointsOctTree(std::vector<std::vector<KP>>& allKeypoints) {
+    allKeypoints.assign(nlevels, std::vector<KP>());
+    candidates.assign(nlevels, std::vector<KP>());
+    const float         W = 35;
+    std::vector<FastPt> vKeysCell;
+    for (int level = 0; level < nlevels; ++level) {
+      const Img& im         = pyramid[level];
+      const int  minBorderX = EDGE_THRESHOLD - 3;
+      const int  minBorderY = minBorderX;
+      const int  maxBorderX = im.w - EDGE_THRESHOLD + 3;
+      const int  maxBorderY = im.h - EDGE_THRESHOLD + 3;
+      std::vector<KP>& vToDistributeKeys = candidates[level];
+      vToDistributeKeys.reserve(nfeatures * 10);
+      const float width  = (float)(maxBorderX - minBorderX);
+      const float height = (float)(maxBorderY - minBorderY);
+      const int   nCols  = (int)(width / W);
+      const int   nRows  = (int)(height / W);
+      if (nCols <= 0 || nRows <= 0) {
+        // width / nCols would be inf -> the reference's behaviour is undefined for levels narrower than 35 px
+        // of usable area; treat as "no cells" (documented deviation, never hit by the supported configs).
+        continue;
+      }
+      const int wCell = (int)std::ceil(width / nCols);
+      const int hCell = (int)std::ceil(height / nRows);
+      for (int i = 0; i < nRows; i++) {
+        const float iniY = (float)(minBorderY + i * hCell);
+        float       maxY = iniY + hCell + 6;
+        if (iniY >= maxBorderY - 3) continue;
+        if (maxY > maxBorderY) maxY = (float)maxBorderY;
+        for (int j = 0; j < nCols; j++) {
+          const float iniX = (float)(minBorderX + j * wCell);
+          float       maxX = iniX + wCell + 6;
+          if (iniX >= maxBorderX - 6) continue;
+          if (maxX > maxBorderX) maxX = (float)maxBorderX;
+          const int x0 = (int)iniX, x1 = (int)maxX, y0 = (int)iniY, y1 = (int)maxY;
+          fast9_16(im.row(y0) + x0, x1 - x0, y1 - y0, im.w, iniThFAST, vKeysCell);
+          if (vKeysCell.empty()) fast9_16(im.row(y0) + x0, x1 - x0, y1 - y0, im.w, minThFAST, vKeysCell);
+          for (const FastPt& p : vKeysCell) {
+            KP kp;
+            kp.x        = (float)p.x;
+            kp.y        = (float)p.y;
+            kp.response = (float)p.score;
+            kp.x += j * wCell;
+            kp.y += i * hCell;
+            kp.src = (int)vToDistributeKeys.size();
+            vToDistributeKeys.push_back(kp);
+          }
+        }
+      }
+      std::vector<KP>& keypoints = allKeypoints[level];
+      if (!distributeOctTree(vToDistributeKeys, minBorderX, maxBorderX, minBorderY, maxBorderY, mnFeaturesPerLevel[level], keypoints))
+        return false;
+      const int scaledPatchSize = (int)(PATCH_SIZE * mvScaleFactor[level]);
+      for (KP& kp : keypoints) {
+        kp.x += minBorderX;
+        kp.y += minBorderY;
+        kp.octave = level;
+        kp.size   = (float)scaledPatchSize;
+      }
+    }
+    for (int level = 0; level < nlevels; ++level) {
+      const Img& im = pyramid[level];
+      for (KP& kp : allKeypoints[level]) kp.angle = icAngle(im.d.data(), im.w, cvRoundF(kp.x), cvRoundF(kp.y), umax.data());
+    }
+    return true;
+  }
+
+  // operator() (src/ORBextractor.cc:1052-1138)
+  int extract(const uint8_t* img, int rows, int cols, size_t step, int lap0, int lap1, orao_keypoint_t* kps, uint8_t* desc,
+              int cap, int* n_out) {
+    if (n_out) *n_out = 0;
+    if (!img || rows <= 0 || cols <= 0) return -1;
+    computePyramid(img, rows, cols, step);
+    std::vector<std::vector<KP>> allKeypoints;
+    if (!computeKeyPointsOctTree(allKeypoints)) return -2;
+    int nkeypoints = 0;
+    for (int level = 0; level < nlevels; ++level) nkeypoints += (int)allKeypoints[level].size();
+    if (nkeypoints > cap) return -2;
+    if (n_out) *n_out = nkeypoints;
+    int monoIndex = 0, stereoIndex = nkeypoints - 1;
+    uint8_t d[32];
+    for (int level = 0; level < nlevels; ++level) {
+      std::vector<KP>& keypoints = allKeypoints[level];
+      const Img&       im        = pyramid[level];
+      blurred[level].alloc(im.w, im.h);
+      // the reference only blurs levels that own keypoints; blurring all of them yields the same descriptors
+      gaussianBlur7(im.d.data(), im.w, im.h, im.w, blurred[level].d.data(), im.w);
+      float scale = mvScaleFactor[level];
+      for (KP& kp : keypoints) {
+        orbDescriptor(blurred[level].d.data(), im.w, cvRoundF(kp.x), cvRoundF(kp.y), kp.angle, d);
+        KP o = kp;
+        if (level != 0) {
+          o.x *= scale;
+          o.y *= scale;
+        }
+        int idx;
+        if (o.x >= lap0 && o.x <= lap1)
+          idx = stereoIndex--;
+        else
+          idx = monoIndex++;
+        kps[idx] = {o.x, o.y, o.size, o.angle, o.response, o.octave, o.class_id};
+        memcpy(desc + (size_t)idx * 32, d, 32);
+      }
+    }
+    levelKps = allKeypoints;
+    return monoIndex;
+  }
+};
+
+extern "C" {
+
+orao_extractor_t* orao_create(int nfeatures, float scale_factor, int nlevels, int ini_th_fast, int min_th_fast) {
+  if (nlevels < 1 || nlevels > 32 || nfeatures < 0 || !(scale_factor > 1.0f)) return nullptr;
+  return new orao_extractor(nfeatures, scale_factor, nlevels, ini_th_fast, min_th_fast);
+}
+void orao_destroy(orao_extractor_t* e) { delete e; }
+
+int orao_extract(orao_extractor_t* e, const uint8_t* img, int rows, int cols, size_t step, int lap0, int lap1,
+                 orao_keypoint_t* kps, uint8_t* desc, int cap, int* n_out) {
+  return e->extract(img, rows, cols, step, lap0, lap1, kps, desc, cap, n_out);
+}
+int  orao_get_levels(const orao_extractor_t* e) { return e->nlevels; }
+void orao_get_scale_tables(const orao_extractor_t* e, float* sf, float* inv_sf, float* sigma2, float* inv_sigma2) {
+  for (int i = 0; i < e->nlevels; i++) {
+    if (sf) sf[i] = e->mvScaleFactor[i];
+    if (inv_sf) inv_sf[i] = e->mvInvScaleFactor[i];
+    if (sigma2) sigma2[i] = e->mvLevelSigma2[i];
+    if (inv_sigma2) inv_sigma2[i] = e->mvInvLevelSigma2[i];
+  }
+}
+void orao_get_features_per_level(const orao_extractor_t* e, int* out) {
+  for (int i = 0; i < e->nlevels; i++) out[i] = e->mnFeaturesPerLevel[i];
+}
+void orao_get_umax(const orao_extractor_t* e, int* out16) {
+  for (int i = 0; i < 16; i++) out16[i] = e->umax[i];
+}
+static int copyLevel(const std::vector<Img>& v, int level, uint8_t* dst, size_t dst_step, int* rows, int* cols) {
+  if (level < 0 || level >= (int)v.size() || v[level].w == 0) return -2;
+  const Img& im = v[level];
+  if (rows) *rows = im.h;
+  if (cols) *cols = im.w;
+  if (dst)
+    for (int y = 0; y < im.h; y++) memcpy(dst + (size_t)y * dst_step, im.row(y), im.w);
+  return 0;
+}
+int orao_pyramid_level(const orao_extractor_t* e, int level, uint8_t* dst, size_t dst_step, int* rows, int* cols) {
+  return copyLevel(e->pyramid, level, dst, dst_step, rows, cols);
+}
+int orao_blurred_level(const orao_extractor_t* e, int level, uint8_t* dst, size_t dst_step, int* rows, int* cols) {
+  return copyLevel(e->blurred, level, dst, dst_step, rows, cols);
+}
+int orao_level_candidates(const orao_extractor_t* e, int level, int* xs, int* ys, int* resp, int cap) {
+  if (level < 0 || level >= (int)e->candidates.size()) return -2;
+  const std::vector<KP>& c = e->candidates[level];
+  for (int i = 0; i < (int)c.size() && i < cap; i++) {
+    xs[i]   = (int)c[i].x;
+    ys[i]   = (int)c[i].y;
+    resp[i] = (int)c[i].response;
+  }
+  return (int)c.size();
+}
+int orao_level_keypoints(const orao_extractor_t* e, int level, orao_keypoint_t* out, int cap) {
+  if (level < 0 || level >= (int)e->levelKps.size()) return -2;
+  const std::vector<KP>& c = e->levelKps[level];
+  for (int i = 0; i < (int)c.size() && i < cap; i++)
+    out[i] = {c[i].x, c[i].y, c[i].size, c[i].angle, c[i].response, c[i].octave, c[i].src};
+  return (int)c.size();
+}
+
+void orao_resize_linear_8u(const uint8_t* src, int sw, int sh, size_t sstep, uint8_t* dst, int dw, int dh, size_t dstep) {
+  resizeLinear8u(src, sw, sh, sstep, dst, dw, dh, dstep);
+}
+void orao_gaussian_blur7_8u(const uint8_t* src, int w, int h, size_t sstep, uint8_t* dst, size_t dstep) {
+  gaussianBlur7(src, w, h, sstep, dst, dstep);
+}
+int orao_fast9_16(const uint8_t* img, int w, int h, size_t step, int threshold, int* xs, int* ys, int* scores, int cap) {
+  std::vector<FastPt> v;
+  fast9_16(img, w, h, step, threshold, v);
+  for (int i = 0; i < (int)v.size() && i < cap; i++) {
+    xs[i]     = v[i].x;
+    ys[i]     = v[i].y;
+    scores[i] = v[i].score;
+  }
+  return (int)v.size();
+}
+float orao_fast_atan2(float y, float x) { return fastAtan2(y, x); }
+int   orao_cv_round_f(float v) { return cvRoundF(v); }
+float orao_ic_angle(const uint8_t* img, size_t step, int x, int y) {
+  static const int um[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+  return icAngle(img, step, x, y, um);
+}
+void orao_orb_descriptor(const uint8_t* blurred, size_t step, int x, int y, float angle_deg, uint8_t* desc32) {
+  orbDescriptor(blurred, step, x, y, angle_deg, desc32);
+}
+int orao_distribute_octtree(const float* xs, const float* ys, const float* resp, int n, int min_x, int max_x, int min_y,
+                            int max_y, int n_target, int* out_idx, int cap) {
+  std::vector<KP> in(n), out;
+  for (int i = 0; i < n; i++) {
+    in[i].x        = xs[i];
+    in[i].y        = ys[i];
+    in[i].response = resp[i];
+    in[i].src      = i;
+  }
+  if (!distributeOctTree(in, min_x, max_x, min_y, max_y, n_target, out)) return -2;
+  for (int i = 0; i < (int)out.size() && i < cap; i++) out_idx[i] = out[i].src;
+  return (int)out.size();
+}
+
+void orao_libm_sincos_deg(const float* deg, int n, float* cos_out, float* sin_out) {
+  for (int i = 0; i < n; i++) {
+    float angle = deg[i] * factorPI;
+    cos_out[i]  = (float)std::cos(angle);
+    sin_out[i]  = (float)std::sin(angle);
+  }
+}
+
+long orao_sincos_port_mismatches(uint32_t bits_lo, uint32_t bits_hi, int fma_variant, int nthreads, uint32_t* first_bad,
+                                 int* n_first_bad) {
+  if (nthreads < 1) nthreads = 1;
+  std::atomic<long>        bad{0};
+  std::atomic<int>         nfb{0};
+  std::vector<std::thread> th;
+  for (int t = 0; t < nthreads; t++)
+    th.emplace_back([&, t] {
+      long b = 0;
+      for (uint64_t u = (uint64_t)bits_lo + t; u < bits_hi; u += nthreads) {
+        uint32_t bits = (uint32_t)u;
+        float    d;
+        memcpy(&d, &bits, 4);
+        float x = d * factorPI;
+        float s = sinf(x), c = cosf(x), ps, pc;
+        if (fma_variant)
+          orbport::sincosf_port<true>(x, &ps, &pc);
+        else
+          orbport::sincosf_port<false>(x, &ps, &pc);
+        if (memcmp(&s, &ps, 4) || memcmp(&c, &pc, 4)) {
+          b++;
+          int k = nfb++;
+          if (k < 16 && first_bad) first_bad[k] = bits;
+        }
+      }
+      bad += b;
+    });
+  for (auto& t : th) t.join();
+  if (n_first_bad) *n_first_bad = std::min((int)nfb, 16);
+  return bad;
+}
+
+// ------------------------------------------------------------------------------------------------
+// ORBmatcher
+// ------------------------------------------------------------------------------------------------
+// DescriptorDistance (src/ORBmatcher.cc:2075-2089)
+int orao_hamming(const uint8_t* a, const uint8_t* b) {
+  int dist = 0;
+  for (int i = 0; i < 8; i++) {
+    uint32_t pa, pb;
+    memcpy(&pa, a + 4 * i, 4);
+    memcpy(&pb, b + 4 * i, 4);
+    unsigned int v = pa ^ pb;
+    v              = v - ((v >> 1) & 0x55555555);
+    v              = (v & 0x33333333) + ((v >> 2) & 0x33333333);
+    dist += (((v + (v >> 4)) & 0xF0F0F0F) * 0x1010101) >> 24;
+  }
+  return dist;
+}
+
+// ComputeThreeMaxima (src/ORBmatcher.cc:2038-2071)
+void orao_three_maxima(const int* counts, int L, int* pind1, int* pind2, int* pind3) {
+  int ind1 = *pind1, ind2 = *pind2, ind3 = *pind3;
+  int max1 = 0, max2 = 0, max3 = 0;
+  for (int i = 0; i < L; i++) {
+    const int s = counts[i];
+    if (s > max1) {
+      max3 = max2;
+      max2 = max1;
+      max1 = s;
+      ind3 = ind2;
+      ind2 = ind1;
+      ind1 = i;
+    } else if (s > max2) {
+      max3 = max2;
+      max2 = s;
+      ind3 = ind2;
+      ind2 = i;
+    } else if (s > max3) {
+      max3 = s;
+      ind3 = i;
+    }
+  }
+  if (max2 < 0.1f * (float)max1) {
+    ind2 = -1;
+    ind3 = -1;
+  } else if (max3 < 0.1f * (float)max1) {
+    ind3 = -1;
+  }
+  *pind1 = ind1;
+  *pind2 = ind2;
+  *pind3 = ind3;
+}
+
+static const int HISTO_LENGTH = 30;
+
+static inline int rotBin(float a1, float a2) {
+  const float factor = 1.0f / HISTO_LENGTH;
+  float       rot    = a1 - a2;
+  if (rot < 0.0) rot += 360.0f;
+  int bin = (int)std::round(rot * factor);
+  if (bin == HISTO_LENGTH) bin = 0;
+  return bin;
+}
+
+// SearchByBoW (src/ORBmatcher.cc:237-421 with F.Nleft == -1, and 784-914)
+int orao_match_groups(const uint8_t* q, int nq, const uint8_t* t, int nt, int ngroups, const int* q_off, const int* q_idx,
+                      const int* t_off, const int* t_idx, const uint8_t* q_valid, const uint8_t* t_valid,
+                      const float* q_angle, const float* t_angle, int th, int strict_lt, float ratio, int check_ori,
+                      int* match_t_of_q, int* match_q_of_t) {
+  std::vector<int> mq(nq, -1), mt(nt, -1);
+  std::vector<int> rotHist[HISTO_LENGTH];
+  int              nmatches = 0;
+  const int        one_q[2] = {0, nq}, one_t[2] = {0, nt};
+  if (ngroups == 1 && !q_off) q_off = one_q;
+  if (ngroups == 1 && !t_off) t_off = one_t;
+  for (int g = 0; g < ngroups; g++) {
+    for (int iq = q_off[g]; iq < q_off[g + 1]; iq++) {
+      const int realIdxQ = q_idx ? q_idx[iq] : iq;
+      if (q_valid && !q_valid[realIdxQ]) continue;
+      const uint8_t* dQ        = q + (size_t)realIdxQ * 32;
+      int            bestDist1 = 256, bestIdx = -1, bestDist2 = 256;
+      for (int it = t_off[g]; it < t_off[g + 1]; it++) {
+        const int realIdxT = t_idx ? t_idx[it] : it;
+        if (mt[realIdxT] >= 0) continue;  // vpMapPointMatches[realIdxF] / vbMatched2[idx2]
+        if (t_valid && !t_valid[realIdxT]) continue;
+        const int dist = orao_hamming(dQ, t + (size_t)realIdxT * 32);
+        if (dist < bestDist1) {
+          bestDist2 = bestDist1;
+          bestDist1 = dist;
+          bestIdx   = realIdxT;
+        } else if (dist < bestDist2) {
+          bestDist2 = dist;
+        }
+      }
+      const bool pass = strict_lt ? (bestDist1 < th) : (bestDist1 <= th);
+      if (pass) {
+        if (static_cast<float>(bestDist1) < ratio * static_cast<float>(bestDist2)) {
+          mt[bestIdx]  = realIdxQ;
+          mq[realIdxQ] = bestIdx;
+          if (check_ori) {
+            int bin = rotBin(q_angle[realIdxQ], t_angle[bestIdx]);
+            rotHist[bin].push_back(realIdxQ);
+          }
+          nmatches++;
+        }
+      }
+    }
+  }
+  if (check_ori) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    int counts[HISTO_LENGTH];
+    for (int i = 0; i < HISTO_LENGTH; i++) counts[i] = (int)rotHist[i].size();
+    orao_three_maxima(counts, HISTO_LENGTH, &ind1, &ind2, &ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i == ind1 || i == ind2 || i == ind3) continue;
+      for (size_t j = 0; j < rotHist[i].size(); j++) {
+        int iq    = rotHist[i][j];
+        mt[mq[iq]] = -1;
+        mq[iq]     = -1;
+        nmatches--;
+      }
+    }
+  }
+  if (match_t_of_q) memcpy(match_t_of_q, mq.data(), sizeof(int) * nq);
+  if (match_q_of_t) memcpy(match_q_of_t, mt.data(), sizeof(int) * nt);
+  return nmatches;
+}
+
+// SearchForInitialization (src/ORBmatcher.cc:666-782) + Frame grid (src/Frame.cc:524-553, 788-877)
+int orao_match_window(const uint8_t* d1, const orao_keypoint_t* kp1, int n1, const uint8_t* d2, const orao_keypoint_t* kp2,
+                      int n2, float* prev_matched, float mnMinX, float mnMaxX, float mnMinY, float mnMaxY, int windowSize,
+                      int th, float ratio, int check_ori, int* vnMatches12) {
+  const int   GRID_COLS = 64, GRID_ROWS = 48;
+  const float gwInv = static_cast<float>(GRID_COLS) / (mnMaxX - mnMinX);
+  const float ghInv = static_cast<float>(GRID_ROWS) / (mnMaxY - mnMinY);
+  // AssignFeaturesToGrid / PosInGrid
+  std::vector<std::vector<int>> grid((size_t)GRID_COLS * GRID_ROWS);
+  for (int i = 0; i < n2; i++) {
+    int posX = (int)std::round((kp2[i].x - mnMinX) * gwInv);
+    int posY = (int)std::round((kp2[i].y - mnMinY) * ghInv);
+    if (posX < 0 || posX >= GRID_COLS || posY < 0 || posY >= GRID_ROWS) continue;
+    grid[(size_t)posX * GRID_ROWS + posY].push_back(i);
+  }
+  int nmatches = 0;
+  for (int i = 0; i < n1; i++) vnMatches12[i] = -1;
+  std::vector<int> rotHist[HISTO_LENGTH];
+  std::vector<int> vMatchedDistance(n2, INT_MAX), vnMatches21(n2, -1);
+  std::vector<int> vIndices2;
+  for (int i1 = 0; i1 < n1; i1++) {
+    int level1 = kp1[i1].octave;
+    if (level1 > 0) continue;
+    // GetFeaturesInArea(x, y, r, level1, level1)
+    vIndices2.clear();
+    {
+      const float x = prev_matched[2 * i1], y = prev_matched[2 * i1 + 1], r = (float)windowSize;
+      const int   minLevel = level1, maxLevel = level1;
+      const int   nMinCellX = std::max(0, (int)std::floor((x - mnMinX - r) * gwInv));
+      const int   nMaxCellX = std::min(GRID_COLS - 1, (int)std::ceil((x - mnMinX + r) * gwInv));
+      const int   nMinCellY = std::max(0, (int)std::floor((y - mnMinY - r) * ghInv));
+      const int   nMaxCellY = std::min(GRID_ROWS - 1, (int)std::ceil((y - mnMinY + r) * ghInv));
+      if (!(nMinCellX >= GRID_COLS || nMaxCellX < 0 || nMinCellY >= GRID_ROWS || nMaxCellY < 0)) {
+        const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+        for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
+          for (int iy = nMinCellY; iy <= nMaxCellY; iy++) {
+            const std::vector<int>& vCell = grid[(size_t)ix * GRID_ROWS + iy];
+            for (size_t j = 0; j < vCell.size(); j++) {
+              const orao_keypoint_t& kpUn = kp2[vCell[j]];
+              if (bCheckLevels) {
+                if (kpUn.octave < minLevel) continue;
+                if (maxLevel >= 0 && kpUn.octave > maxLevel) continue;
+              }
+              const float distx = kpUn.x - x, disty = kpUn.y - y;
+              if (std::fabs(distx) < r && std::fabs(disty) < r) vIndices2.push_back(vCell[j]);
+            }
+          }
+      }
+    }
+    if (vIndices2.empty()) continue;
+    const uint8_t* dd1      = d1 + (size_t)i1 * 32;
+    int            bestDist = INT_MAX, bestDist2 = INT_MAX, bestIdx2 = -1;
+    for (int i2 : vIndices2) {
+      int dist = orao_hamming(dd1, d2 + (size_t)i2 * 32);
+      if (vMatchedDistance[i2] <= dist) continue;
+      if (dist < bestDist) {
+        bestDist2 = bestDist;
+        bestDist  = dist;
+        bestIdx2  = i2;
+      } else if (dist < bestDist2) {
+        bestDist2 = dist;
+      }
+    }
+    if (bestDist <= th) {
+      if (bestDist < (float)bestDist2 * ratio) {
+        if (vnMatches21[bestIdx2] >= 0) {
+          vnMatches12[vnMatches21[bestIdx2]] = -1;
+          nmatches--;
+        }
+        vnMatches12[i1]            = bestIdx2;
+        vnMatches21[bestIdx2]      = i1;
+        vMatchedDistance[bestIdx2] = bestDist;
+        nmatches++;
+        if (check_ori) rotHist[rotBin(kp1[i1].angle, kp2[bestIdx2].angle)].push_back(i1);
+      }
+    }
+  }
+  if (check_ori) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    int counts[HISTO_LENGTH];
+    for (int i = 0; i < HISTO_LENGTH; i++) counts[i] = (int)rotHist[i].size();
+    orao_three_maxima(counts, HISTO_LENGTH, &ind1, &ind2, &ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i == ind1 || i == ind2 || i == ind3) continue;
+      for (size_t j = 0; j < rotHist[i].size(); j++) {
+        int idx1 = rotHist[i][j];
+        if (vnMatches12[idx1] >= 0) {
+          vnMatches12[idx1] = -1;
+          nmatches--;
+        }
+      }
+    }
+  }
+  for (int i1 = 0; i1 < n1; i1++)
+    if (vnMatches12[i1] >= 0) {
+      prev_matched[2 * i1]     = kp2[vnMatches12[i1]].x;
+      prev_matched[2 * i1 + 1] = kp2[vnMatches12[i1]].y;
+    }
+  return nmatches;
+}
+
+}  // extern "C"

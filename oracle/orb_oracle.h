@@ -1,0 +1,107 @@
+/*
+ * orb_oracle.h -- C interface of the CPU ORACLE for the ORB extract + match hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This is a dependency-free CPU restatement of the
+ * reference algorithm (elkuno213/orbslam3_cpp_fork: src/ORBextractor.cc,
+ * src/ORBmatcher.cc, src/Frame.cc grid queries) plus the OpenCV >= 4.5
+ * primitives the reference calls (cv::resize INTER_LINEAR 8U, cv::FAST 9/16 +
+ * NMS, cv::GaussianBlur 7x7 sigma 2 fixed point, cv::fastAtan2, cvRound).
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may link,
+ * load or call it -- as the checker / timed CPU baseline, never as the product.
+ *
+ * PARITY STATUS: "parity unpinned".  The reference cannot be compiled in the build
+ * container (OpenCV and Eigen are absent), it ships no golden vectors or
+ * known-answer tests for this path (its test/ directory never constructs an
+ * extractor or matcher), and OpenCV itself is an un-vendored system dependency
+ * (find_package(OpenCV 4.4), CMakeLists.txt:21).  The oracle is therefore pinned
+ * only by analytic known-answer tests (tests/test_oracle_kats.py) and by
+ * self-consistency; restatement-vs-OpenCV equality is unverified.
+ */
+#ifndef ORB_ORACLE_H_
+#define ORB_ORACLE_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Same 28-byte layout as cv::KeyPoint {pt.x, pt.y, size, angle, response, octave, class_id}. */
+typedef struct {
+  float x, y, size, angle, response;
+  int   octave, class_id;
+} orao_keypoint_t;
+
+typedef struct orao_extractor orao_extractor_t;
+
+/* ORBextractor::ORBextractor (src/ORBextractor.cc:403-465) */
+orao_extractor_t* orao_create(int nfeatures, float scale_factor, int nlevels, int ini_th_fast, int min_th_fast);
+void              orao_destroy(orao_extractor_t*);
+
+/* ORBextractor::operator() (src/ORBextractor.cc:1052-1138).  Returns monoIndex (>=0), -1 on an
+ * empty image, -2 on bad arguments (nIni == 0 hazard, cap too small). */
+int orao_extract(orao_extractor_t*, const uint8_t* img, int rows, int cols, size_t step, int lap0, int lap1,
+                 orao_keypoint_t* kps, uint8_t* desc, int cap, int* n_out);
+
+int  orao_get_levels(const orao_extractor_t*);
+void orao_get_scale_tables(const orao_extractor_t*, float* sf, float* inv_sf, float* sigma2, float* inv_sigma2);
+void orao_get_features_per_level(const orao_extractor_t*, int* out);
+void orao_get_umax(const orao_extractor_t*, int* out16);
+/* mvImagePyramid[level] of the last extract (interior ROI, no border). */
+int orao_pyramid_level(const orao_extractor_t*, int level, uint8_t* dst, size_t dst_step, int* rows, int* cols);
+/* Blurred level of the last extract (what computeDescriptors reads). */
+int orao_blurred_level(const orao_extractor_t*, int level, uint8_t* dst, size_t dst_step, int* rows, int* cols);
+/* Candidates fed to DistributeOctTree for `level` in the last extract, in feed order
+ * (coordinates relative to minBorder, as in src/ORBextractor.cc:842-848).  Returns the count. */
+int orao_level_candidates(const orao_extractor_t*, int level, int* xs, int* ys, int* resp, int cap);
+/* Keypoints of `level` after DistributeOctTree + orientation (level coordinates, natural order). */
+int orao_level_keypoints(const orao_extractor_t*, int level, orao_keypoint_t* out, int cap);
+
+/* ---- primitives, exposed for known-answer tests ---- */
+void  orao_resize_linear_8u(const uint8_t* src, int sw, int sh, size_t sstep, uint8_t* dst, int dw, int dh, size_t dstep);
+void  orao_gaussian_blur7_8u(const uint8_t* src, int w, int h, size_t sstep, uint8_t* dst, size_t dstep);
+int   orao_fast9_16(const uint8_t* img, int w, int h, size_t step, int threshold, int* xs, int* ys, int* scores, int cap);
+float orao_fast_atan2(float y, float x);
+int   orao_cv_round_f(float v);
+float orao_ic_angle(const uint8_t* img, size_t step, int x, int y);
+void  orao_orb_descriptor(const uint8_t* blurred, size_t step, int x, int y, float angle_deg, uint8_t* desc32);
+/* DistributeOctTree (src/ORBextractor.cc:556-753): returns the number of kept points, their indices
+ * into the input arrays in output (list) order.  -2 if nIni == 0. */
+int orao_distribute_octtree(const float* xs, const float* ys, const float* resp, int n, int min_x, int max_x,
+                            int min_y, int max_y, int n_target, int* out_idx, int cap);
+/* libm (cosf, sinf) of this host for x = deg * (float)(CV_PI/180.f), as computeOrbDescriptor uses them
+ * (src/ORBextractor.cc:93,97-98).  Bulk form for the exhaustive device-port check. */
+void orao_libm_sincos_deg(const float* deg, int n, float* cos_out, float* sin_out);
+/* Number of float inputs `deg` in [bits_lo, bits_hi) (IEEE bit patterns of non-negative floats) for which
+ * the given port (0 = plain double, 1 = FMA-contracted double) differs from this host's libm. Multi-threaded. */
+long orao_sincos_port_mismatches(uint32_t bits_lo, uint32_t bits_hi, int fma_variant, int nthreads,
+                                 uint32_t* first_bad /* up to 16 entries */, int* n_first_bad);
+
+/* ---- matcher ---- */
+/* ORBmatcher::DescriptorDistance (src/ORBmatcher.cc:2075-2089) */
+int orao_hamming(const uint8_t* a32, const uint8_t* b32);
+/* ORBmatcher::ComputeThreeMaxima (src/ORBmatcher.cc:2038-2071) on bin counts. */
+void orao_three_maxima(const int* counts, int L, int* ind1, int* ind2, int* ind3);
+/* ORBmatcher::SearchByBoW, both overloads (src/ORBmatcher.cc:237-421 mono branch, 784-914), over flattened
+ * FeatureVector groups.  Group g pairs query indices q_idx[q_off[g]..q_off[g+1]) with train indices
+ * t_idx[t_off[g]..t_off[g+1]).  q_idx/t_idx may be NULL when ngroups == 1 (identity lists).
+ * q_valid / t_valid: 1 = has a good MapPoint (NULL = all valid).  strict_lt: 0 -> best <= th (Frame
+ * overload), 1 -> best < th (KeyFrame overload).  Outputs: match_t_of_q[nq] and match_q_of_t[nt]
+ * (-1 = none; either may be NULL).  Returns nmatches. */
+int orao_match_groups(const uint8_t* q, int nq, const uint8_t* t, int nt, int ngroups, const int* q_off,
+                      const int* q_idx, const int* t_off, const int* t_idx, const uint8_t* q_valid,
+                      const uint8_t* t_valid, const float* q_angle, const float* t_angle, int th, int strict_lt,
+                      float ratio, int check_ori, int* match_t_of_q, int* match_q_of_t);
+/* ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:666-782) with the Frame grid restated
+ * (src/Frame.cc:524-553, 788-877; 64x48 grid over [min_x,max_x]x[min_y,max_y]).
+ * kp1/kp2: keypoints (x, y, angle, octave); prev_matched: nq x 2 floats, updated in place
+ * (:775-779).  matches12[n1] out.  Returns nmatches. */
+int orao_match_window(const uint8_t* d1, const orao_keypoint_t* kp1, int n1, const uint8_t* d2,
+                      const orao_keypoint_t* kp2, int n2, float* prev_matched, float min_x, float max_x, float min_y,
+                      float max_y, int window, int th, float ratio, int check_ori, int* matches12);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,127 @@
+"""Deterministic synthetic camera frames ("Synthetic inputs").
+
+There is no dataset in the build/measurement environment, so every config of BASELINE.json runs on
+seeded synthetic grayscale frames: multi-octave value-noise texture + random rectangles (FAST corners)
++ flat regions (exercise the minThFAST fallback and empty cells).  Streams translate by an integer
+offset per frame with a small brightness jitter so that consecutive frames match.
+"""
+import numpy as np
+
+BASE_SEED = 20251004
+
+
+def _upsample_bilinear(lat, h, w):
+    lh, lw = lat.shape
+    ys = np.linspace(0, lh - 1, h, dtype=np.float32)
+    xs = np.linspace(0, lw - 1, w, dtype=np.float32)
+    y0 = np.clip(np.floor(ys).astype(np.int32), 0, lh - 2)
+    x0 = np.clip(np.floor(xs).astype(np.int32), 0, lw - 2)
+    fy = (ys - y0)[:, None]
+    fx = (xs - x0)[None, :]
+    a = lat[y0][:, x0]
+    b = lat[y0][:, x0 + 1]
+    c = lat[y0 + 1][:, x0]
+    d = lat[y0 + 1][:, x0 + 1]
+    return (a * (1 - fx) + b * fx) * (1 - fy) + (c * (1 - fx) + d * fx) * fy
+
+
+def make_world(height, width, seed, n_rects=400, flat_frac=0.15):
+    """One large u8 canvas; frames are crops of it."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    acc = np.zeros((height, width), np.float32)
+    amp = 1.0
+    for o in range(6):
+        lh, lw = max(2, (height >> (7 - o)) + 2), max(2, (width >> (7 - o)) + 2)
+        lat = rng.integers(0, 256, size=(lh, lw)).astype(np.float32)
+        acc += amp * _upsample_bilinear(lat, height, width)
+        amp *= 0.6
+    acc -= acc.min()
+    acc *= 255.0 / max(acc.max(), 1e-6)
+    img = acc
+    # rectangles: axis-aligned and rotated, random gray
+    yy, xx = np.mgrid[0:height, 0:width].astype(np.float32)
+    for i in range(n_rects):
+        cx, cy = rng.uniform(0, width), rng.uniform(0, height)
+        hw, hh = rng.uniform(4, 40), rng.uniform(4, 40)
+        g = rng.uniform(0, 255)
+        if i % 2 == 0:
+            x0, x1 = int(max(cx - hw, 0)), int(min(cx + hw, width))
+            y0, y1 = int(max(cy - hh, 0)), int(min(cy + hh, height))
+            img[y0:y1, x0:x1] = g
+        else:
+            th = rng.uniform(0, np.pi)
+            r = int(np.hypot(hw, hh)) + 2
+            x0, x1 = int(max(cx - r, 0)), int(min(cx + r, width))
+            y0, y1 = int(max(cy - r, 0)), int(min(cy + r, height))
+            if x1 <= x0 or y1 <= y0:
+                continue
+            dx = xx[y0:y1, x0:x1] - cx
+            dy = yy[y0:y1, x0:x1] - cy
+            u = dx * np.cos(th) + dy * np.sin(th)
+            v = -dx * np.sin(th) + dy * np.cos(th)
+            m = (np.abs(u) < hw) & (np.abs(v) < hh)
+            sub = img[y0:y1, x0:x1]
+            sub[m] = g
+    # flat regions
+    area, target = 0, flat_frac * height * width
+    while area < target:
+        fw, fh = int(rng.uniform(40, width / 3)), int(rng.uniform(40, height / 3))
+        x0, y0 = int(rng.uniform(0, width - fw)), int(rng.uniform(0, height - fh))
+        img[y0:y0 + fh, x0:x0 + fw] = rng.uniform(30, 220)
+        area += fw * fh
+    return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+
+def make_frame(height, width, camera_idx=0, frame_idx=0):
+    """Independent frame with seed = BASE_SEED + 1000*camera + frame (config 2 / 5 style)."""
+    return make_world(height, width, BASE_SEED + 1000 * camera_idx + frame_idx)
+
+
+def make_stream(height, width, n_frames, camera_idx=0, max_shift=8):
+    """Translating stream (config 3): crops of one world + brightness jitter of +-3."""
+    seed = BASE_SEED + 1000 * camera_idx
+    rng = np.random.Generator(np.random.PCG64(seed + 7))
+    margin = max_shift * n_frames + 8
+    world = make_world(height + margin, width + margin, seed)
+    frames = np.empty((n_frames, height, width), np.uint8)
+    ox = oy = 0
+    for f in range(n_frames):
+        crop = world[oy:oy + height, ox:ox + width].astype(np.int16) + int(rng.integers(-3, 4))
+        frames[f] = np.clip(crop, 0, 255).astype(np.uint8)
+        ox = min(ox + int(rng.integers(0, max_shift + 1)), margin - 1)
+        oy = min(oy + int(rng.integers(0, max_shift + 1)), margin - 1)
+    return frames
+
+
+def make_stereo_pair(height, width, camera_idx=0, frame_idx=0, max_disp=60):
+    """Left image + right image shifted by a per-row-constant disparity in [5, max_disp] (config 4)."""
+    seed = BASE_SEED + 1000 * camera_idx + frame_idx
+    rng = np.random.Generator(np.random.PCG64(seed + 13))
+    world = make_world(height, width + max_disp, seed)
+    left = world[:, max_disp:max_disp + width].copy()
+    right = np.empty_like(left)
+    # piecewise-constant disparity over bands of rows
+    y = 0
+    while y < height:
+        band = int(rng.integers(8, 48))
+        d = int(rng.integers(5, max_disp + 1))
+        right[y:y + band] = world[y:y + band, max_disp - d:max_disp - d + width]
+        y += band
+    return left, right
+
+
+def random_descriptors(n, seed):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    return rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+
+
+def planted_descriptors(train, seed, max_flips=60):
+    """Each query = a train row with k in [0, max_flips] random bit flips."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    q = train.copy()
+    for i in range(len(q)):
+        k = int(rng.integers(0, max_flips + 1))
+        bits = rng.choice(256, size=k, replace=False)
+        for b in bits:
+            q[i, b >> 3] ^= np.uint8(1 << (b & 7))
+    return q
