@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/s of the ORB extract + match hot path on MI355X (BASELINE.json metric).
+
+Workload at N = 1 (BASELINE.json configs[1] + the matching half of the metric): a synthetic 640x480 8-bit
+camera stream, ORBextractor(1000 features, 1.2, 8 levels, iniThFAST 20, minThFAST 7), every frame matched
+against its predecessor with the brute-force SearchByBoW loop (TH_LOW 50, ratio 0.7, rotation check).
+A "step" = one chunk of --frames frames already resident in HBM: 6 extractor kernels classes + 2 matcher
+kernels over the whole chunk.  With N > 1 every rank runs the same chunk size on its own camera (weak
+scaling, the path shards by frame) and the keypoints/descriptors are gathered to rank 0 over RCCL.
+
+Prints ONE JSON line (rank 0).  `value` = frames of all ranks / max-over-ranks wall time of the timed steps.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+WORKLOADS = {
+    # name: (rows, cols, nfeatures)
+    "vga_stream_640x480_8lvl_1000feat_extract+match": (480, 640, 1000),
+    "euroc_stream_752x480_8lvl_1000feat_extract+match": (480, 752, 1000),
+    "rig_1920x1080_8lvl_1000feat_extract+match": (1080, 1920, 1000),
+}
+
+
+def level_sizes(rows, cols, nlevels=8, scale=1.2):
+    """Per-level (w, h) with the constructor's float32 sequence (reference src/ORBextractor.cc:409-425, 1142-1143)."""
+    sf = np.float32(1.0)
+    out = []
+    for _ in range(nlevels):
+        inv = np.float32(1.0) / sf
+        out.append((int(np.rint(np.float32(cols) * inv)), int(np.rint(np.float32(rows) * inv))))
+        sf = np.float32(sf * np.float32(scale))
+    return out
+
+
+def algorithmic_bytes(rows, cols, nfeatures, nlevels=8):
+    """HBM bytes one frame must move, split per kernel class."""
+    P = [w * h for w, h in level_sizes(rows, cols, nlevels)]
+    S = sum(P)
+    return {
+        "pyramid": sum(P[:-1]) + sum(P[1:]),  # read level l-1, write level l
+        "fast": S,  # every level read once
+        "blur": 2 * S,  # read + write
+        "output": 48 * nfeatures,  # 16 B keypoint + 32 B descriptor
+        "total": sum(P[:-1]) + sum(P[1:]) + 3 * S + 48 * nfeatures,
+    }
+
+
+def cpu_baseline(frames, nfeatures, budget_s=12.0):
+    """Single-thread CPU restatement (oracle/, kind "port") on a bounded sample of the same stream."""
+    from oracle import oracle_py as O
+
+    ex = O.OracleExtractor(nfeatures, 1.2, 8, 20, 7)
+    prev = None
+    t0 = time.perf_counter()
+    done = 0
+    for f in range(len(frames)):
+        rc, k, d = ex(frames[f], (0, 1000))
+        if prev is not None:
+            O.match_groups(prev[1], d, prev[0]["angle"], k["angle"], th=50, ratio=0.7, strict_lt=False, check_ori=True)
+        prev = (k, d)
+        done += 1
+        if time.perf_counter() - t0 > budget_s and done >= 8:
+            break
+    dt = time.perf_counter() - t0
+    return {
+        "value": round(done / dt, 3),
+        "unit": "frames/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": "%d frames of the same synthetic stream, extract + match vs previous frame, oracle/orb_oracle.cpp single thread (-O3 -march=x86-64-v3 -ffp-contract=off), %.1f s" % (done, dt),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=64, help="frames per step and per GPU (resident in HBM)")
+    ap.add_argument("--workload", default="vga_stream_640x480_8lvl_1000feat_extract+match", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-match", action="store_true", help="extract only")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from orbslam3_cpp_fork_amd import shard, synth
+    from orbslam3_cpp_fork_amd.extractor import ORBextractor
+    from orbslam3_cpp_fork_amd.matcher import ORBmatcher
+
+    rows, cols, nfeat = WORKLOADS[args.workload]
+    B = args.frames
+    # one camera per rank (frames shard by camera; consecutive frames of a camera stay on one GPU for matching)
+    frames_np = synth.make_stream(rows, cols, B, camera_idx=shard.camera_of_rank(rank, world))
+    d_imgs = torch.from_numpy(frames_np).to(dev)
+
+    ex = ORBextractor(nfeat, 1.2, 8, 20, 7, device=local_rank)
+    mt = ORBmatcher(0.7, True, device=local_rank)
+    cap = ex.max_keypoints(rows, cols)
+    d_kps = torch.zeros((B, cap, 7), dtype=torch.float32, device=dev)
+    d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
+    d_cnt = torch.zeros((B, 2), dtype=torch.int32, device=dev)
+    pairs = np.stack([(np.arange(B) - 1) % B, np.arange(B)], 1).astype(np.int32)  # frame f-1 (query) vs frame f (train)
+    d_pairs = torch.from_numpy(pairs).to(dev)
+    d_match = torch.full((B, cap), -1, dtype=torch.int32, device=dev)
+    d_nm = torch.zeros(B, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    gather = shard.RecordGather(B, cap, dev, world, rank) if world > 1 else None
+
+    def step():
+        ex.extract_batch_device(d_imgs, B, rows, cols, cols, rows * cols, d_kps, d_desc, d_cnt, cap, (0, 1000), stream=stream)
+        if not args.no_match:
+            mt.match_pairs_device(d_desc, d_kps, d_cnt, cap, d_pairs, B, d_match, d_nm, stream=stream)
+        if gather is not None:
+            gather(d_kps, d_desc, d_cnt)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ex.set_profiling(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    stage = ex.stage_ms()
+    ex.set_profiling(False)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    total_frames = B * args.steps * world
+    value = total_frames / dt
+    cnt = d_cnt.cpu().numpy()
+    nm = d_nm.cpu().numpy()
+
+    if rank == 0:
+        ab = algorithmic_bytes(rows, cols, nfeat)
+        # dominant kernel class = the stage with the largest mean HIP-event duration in the timed region
+        kernels = {"pyramid": "k_resize_level", "fast": "k_fast_cells", "octree": "k_octree", "blur": "k_blur_levels", "orient_describe": "k_orient_describe"}
+        dom = max(kernels, key=lambda k: stage[k])
+        # algorithmic HBM bytes of that kernel for one launch (= B frames); kernels without a streaming term move
+        # only the keypoint records (quadtree) or gather through L2 (orientation/BRIEF): price those by the output term.
+        per_frame = ab.get(dom, ab["output"])
+        achieved = per_frame * B / (stage[dom] * 1e-3) / 1e9
+        out = {
+            "metric": "frames/s ORB extract+match (640x480, 8 lvl, 1000 feat)" if cols == 640 else "frames/s ORB extract+match",
+            "value": round(value, 2),
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic",
+            "config": {
+                "workload": args.workload + ("" if not args.no_match else " [extract only]"),
+                "frames_per_step_per_gpu": B,
+                "rows": rows,
+                "cols": cols,
+                "nfeatures": nfeat,
+                "nlevels": 8,
+                "parallelism": "frames sharded by camera, %d rank(s)%s" % (world, ", RCCL gather of keypoints+descriptors to rank 0" if world > 1 else ""),
+                "keypoints_per_frame": float(cnt[:, 0].mean()),
+                "matches_per_frame": float(nm.mean()) if not args.no_match else None,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": kernels[dom],
+                "achieved": round(achieved, 3),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 6),
+                "traffic": None,
+                "algorithmic_bytes_per_launch": per_frame * B,
+                "avg_launch_ms": round(stage[dom], 5),
+            },
+            "stage_ms": {k: round(v, 5) for k, v in stage.items()},
+            "pipeline_hbm": {
+                "algorithmic_bytes_per_frame": ab["total"],
+                "achieved_GBps": round(ab["total"] * value / world / 1e9, 3),
+                "frac_of_peak": round(ab["total"] * value / world / 1e9 / HBM_PEAK_GBS, 6),
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(frames_np, nfeat)
+            out["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,144 @@
+/*
+ * orbx.h -- C ABI of the MI355X-native ORB front-end (orbx_*) and Hamming matcher (orbm_*).
+ *
+ * This is the drop-in boundary for ORB-SLAM3's hot path (reference: elkuno213/orbslam3_cpp_fork).
+ * The reference has no FFI/plugin layer; the seam is the C++ class `ORB_SLAM3::ORBextractor`
+ * (include/ORBextractor.h:41-119, sole call site src/Frame.cc:555-562) and the inner loops of
+ * `ORB_SLAM3::ORBmatcher` (include/ORBmatcher.h:35-148).  Every entry point below names the reference
+ * interface it replaces.  Plain pointers and sizes only; no C++ or torch types.  The C++ adaptor
+ * classes with the reference's own signatures live in include/orbslam3_amd/.
+ *
+ * Return codes: >= 0 success (orbx_extract: monoIndex as the reference returns it),
+ *   -1 empty image (src/ORBextractor.cc:1060-1062), -2 bad arguments, -3 HIP runtime error
+ *   (message via orbx_last_error()).  Nothing throws across this boundary.
+ *
+ * Threading (src/Frame.cc:202-205): one handle = one HIP stream and one set of device buffers; two
+ * handles may be driven concurrently from two threads (stereo left/right), one handle may not.
+ */
+#ifndef ORBX_H_
+#define ORBX_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* cv::KeyPoint layout (28 bytes): the adaptor memcpy's these into std::vector<cv::KeyPoint>. */
+typedef struct {
+  float x, y, size, angle, response;
+  int   octave, class_id;
+} orbx_keypoint_t;
+
+typedef struct orbx_extractor orbx_t;
+
+/* ---- ORBextractor ---------------------------------------------------------------------------- */
+
+/* ORBextractor::ORBextractor(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST)
+ * (src/ORBextractor.cc:403-465; constructed at src/Tracking.cc:576-585). */
+int  orbx_create(orbx_t** out, int nfeatures, float scale_factor, int nlevels, int ini_th_fast, int min_th_fast, int device_id);
+void orbx_destroy(orbx_t* h);
+const char* orbx_last_error(void);
+
+/* GetLevels / GetScaleFactors / GetInverseScaleFactors / GetScaleSigmaSquares /
+ * GetInverseScaleSigmaSquares (include/ORBextractor.h:63-85); any pointer may be NULL. */
+int  orbx_get_levels(const orbx_t* h);
+void orbx_get_scale_tables(const orbx_t* h, float* scale, float* inv_scale, float* sigma2, float* inv_sigma2);
+void orbx_get_features_per_level(const orbx_t* h, int* out);
+
+/* Upper bound on keypoints one image of this size can yield (sum over levels of max(N_l + 3, 4 nIni_l));
+ * output buffers of orbx_extract* must hold at least this many entries. -2 if the size is unsupported. */
+int orbx_max_keypoints(orbx_t* h, int rows, int cols);
+
+/* ORBextractor::operator()(image, mask [ignored], keypoints, descriptors, vLappingArea)
+ * (src/ORBextractor.cc:1052-1138).  Host image in, host results out; synchronous.
+ * kps / desc are caller-owned (cap entries, desc is cap x 32 bytes); *n_out = number of keypoints.
+ * Returns monoIndex (:1137). */
+int orbx_extract(orbx_t* h, const uint8_t* img, int rows, int cols, size_t step_bytes, int lap0, int lap1,
+                 orbx_keypoint_t* kps, uint8_t* desc, int cap, int* n_out);
+
+/* The same operator over a batch of frames that are already resident in device memory (a camera rig or
+ * a stream chunk): frame f starts at d_imgs + f * frame_stride_bytes, rows of step_bytes.  Results stay
+ * on the device: d_kps[f * cap + i], d_desc[(f * cap + i) * 32], d_counts[2 f] = n, d_counts[2 f + 1] =
+ * monoIndex.  Only enqueues work on `stream` (a hipStream_t; NULL = the handle's own stream); the caller
+ * synchronises.  Input buffers must stay valid until then. */
+int orbx_extract_batch_device(orbx_t* h, const uint8_t* d_imgs, int nframes, int rows, int cols, size_t step_bytes,
+                              size_t frame_stride_bytes, int lap0, int lap1, orbx_keypoint_t* d_kps, uint8_t* d_desc,
+                              int* d_counts, int cap, void* stream);
+
+/* mvImagePyramid[level] (public member, include/ORBextractor.h:87; read by Frame::ComputeStereoMatches,
+ * src/Frame.cc:950,1039-1058) of frame `frame` of the last extract call: copies the level to host memory.
+ * dst may be NULL to query the size. */
+int orbx_pyramid_level(orbx_t* h, int frame, int level, uint8_t* dst, size_t dst_step, int* rows, int* cols);
+
+/* Stage timing with HIP events recorded on the launch stream between the kernels of every batch:
+ * enable (resets the record), run batches, then read the mean milliseconds per stage over the batches
+ * recorded since (at most the last 32); returns the number of batches averaged.  Stages: 0 pyramid
+ * (all resize launches), 1 FAST, 2 quadtree, 3 layout, 4 blur, 5 orientation+descriptor, 6 whole batch. */
+#define ORBX_NUM_STAGES 7
+void orbx_set_profiling(orbx_t* h, int enable);
+int  orbx_get_stage_ms(orbx_t* h, float* ms /* ORBX_NUM_STAGES */);
+
+/* Parity-test hooks (frame / level of the last call): blurred level, the candidate feed of
+ * DistributeOctTree (packed x | y << 12 | response << 24, minBorder-relative), and the per-level
+ * keypoints after the quadtree in list order (same packing).  Each returns the element count. */
+int orbx_debug_blurred_level(orbx_t* h, int frame, int level, uint8_t* dst, size_t dst_step, int* rows, int* cols);
+int orbx_debug_level_candidates(orbx_t* h, int frame, int level, uint32_t* out, int cap);
+int orbx_debug_level_keypoints(orbx_t* h, int frame, int level, uint32_t* out, int cap);
+/* Device run of DistributeOctTree alone on caller-supplied candidates (host arrays). */
+int orbx_debug_octree_device(orbx_t* h, const uint32_t* cand, int n, int W, int H, int N, uint32_t* out, int* out_count);
+
+/* ---- ORBmatcher ------------------------------------------------------------------------------ */
+
+typedef struct orbm_matcher orbm_t;
+
+int  orbm_create(orbm_t** out, int device_id);
+void orbm_destroy(orbm_t* h);
+
+/* ORBmatcher::DescriptorDistance (src/ORBmatcher.cc:2075-2089); host-side, for the call sites that
+ * compare single pairs (src/Frame.cc:1019, src/MapPoint.cc:426). */
+int orbm_hamming(const uint8_t* a32, const uint8_t* b32);
+
+/* ORBmatcher::ComputeThreeMaxima (src/ORBmatcher.cc:2038-2071) on bin counts. */
+void orbm_three_maxima(const int* counts, int len, int* ind1, int* ind2, int* ind3);
+
+/* ORBmatcher::SearchByBoW, both overloads (src/ORBmatcher.cc:237-421 [F.Nleft == -1] and 784-914), over
+ * flattened DBoW2 FeatureVector groups: group g pairs the query (KeyFrame) features
+ * q_idx[q_off[g] .. q_off[g+1]) with the train (Frame) features t_idx[t_off[g] .. t_off[g+1]).
+ * ngroups == 1 with all four arrays NULL = plain brute force.  q_valid / t_valid: 1 = feature has a good
+ * MapPoint (NULL = all).  strict_lt = 0: best <= th (:319), 1: best < th (:864).  Claims are greedy in query
+ * order as in the reference.  Host pointers, synchronous.  match_t_of_q[nq] / match_q_of_t[nt]: -1 = none;
+ * either may be NULL.  Returns nmatches. */
+int orbm_match_groups(orbm_t* h, const uint8_t* q, int nq, const uint8_t* t, int nt, int ngroups, const int* q_off,
+                      const int* q_idx, const int* t_off, const int* t_idx, const uint8_t* q_valid, const uint8_t* t_valid,
+                      const float* q_angle, const float* t_angle, int th, int strict_lt, float ratio, int check_ori,
+                      int* match_t_of_q, int* match_q_of_t);
+
+/* Device-resident brute-force form (ngroups == 1, all features valid) for streams whose descriptors never
+ * leave the GPU: d_q / d_t are device descriptor arrays, d_q_kp / d_t_kp the device keypoint arrays written
+ * by orbx_extract_batch_device (angles are read from them), d_nq / d_nt device ints with the live counts
+ * (<= cap_q, cap_t).  Writes d_match_t_of_q[cap_q] and d_nmatches[1].  Enqueue only. */
+int orbm_match_bruteforce_device(orbm_t* h, const uint8_t* d_q, const orbx_keypoint_t* d_q_kp, const int* d_nq, int cap_q,
+                                 const uint8_t* d_t, const orbx_keypoint_t* d_t_kp, const int* d_nt, int cap_t, int th,
+                                 int strict_lt, float ratio, int check_ori, int* d_match_t_of_q, int* d_nmatches, void* stream);
+
+/* The same search for many frame pairs of one extraction batch in two launches (a camera stream: frame f-1
+ * against frame f).  d_desc / d_kps / d_counts / cap are the buffers orbx_extract_batch_device filled;
+ * d_pairs holds npairs x {query frame, train frame} (device ints).  Pair p writes d_match_t_of_q[p * cap ..]
+ * and d_nmatches[p].  Enqueue only. */
+int orbm_match_pairs_device(orbm_t* h, const uint8_t* d_desc, const orbx_keypoint_t* d_kps, const int* d_counts, int cap,
+                            const int* d_pairs, int npairs, int th, int strict_lt, float ratio, int check_ori, int* d_match_t_of_q,
+                            int* d_nmatches, void* stream);
+
+/* ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:666-782) including Frame::GetFeaturesInArea over
+ * the 64 x 48 grid (src/Frame.cc:524-553, 788-877).  kp1 / kp2 are undistorted keypoints; prev_matched is
+ * n1 x 2 floats, updated in place (:775-779); bounds = Frame::mnMinX..mnMaxY.  Host pointers, synchronous. */
+int orbm_match_window(orbm_t* h, const uint8_t* d1, const orbx_keypoint_t* kp1, int n1, const uint8_t* d2,
+                      const orbx_keypoint_t* kp2, int n2, float* prev_matched, float min_x, float max_x, float min_y,
+                      float max_y, int window, int th, float ratio, int check_ori, int* matches12);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

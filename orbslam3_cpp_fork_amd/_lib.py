@@ -1,0 +1,96 @@
+"""ctypes loader of liborbx.so (the HIP kernels + C ABI declared in include/orbx.h).
+
+There is no CPU fallback: if the shared library is missing it is built with hipcc, and if that fails, or
+if a compute entry point is called without a GPU, the error propagates.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+KP_DTYPE = np.dtype(
+    [("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")]
+)
+NUM_STAGES = 7
+STAGE_NAMES = ("pyramid", "fast", "octree", "layout", "blur", "orient_describe", "total")
+
+_lib = None
+
+_vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+_ip = C.POINTER(C.c_int)
+
+# name -> (restype, argtypes).  Every symbol include/orbx.h declares is listed (tests check the export table).
+SIGNATURES = {
+    "orbx_create": (_i, [C.POINTER(_vp), _i, _f, _i, _i, _i, _i]),
+    "orbx_destroy": (None, [_vp]),
+    "orbx_last_error": (C.c_char_p, []),
+    "orbx_get_levels": (_i, [_vp]),
+    "orbx_get_scale_tables": (None, [_vp, _vp, _vp, _vp, _vp]),
+    "orbx_get_features_per_level": (None, [_vp, _vp]),
+    "orbx_max_keypoints": (_i, [_vp, _i, _i]),
+    "orbx_extract": (_i, [_vp, _vp, _i, _i, _sz, _i, _i, _vp, _vp, _i, _ip]),
+    "orbx_extract_batch_device": (_i, [_vp, _vp, _i, _i, _i, _sz, _sz, _i, _i, _vp, _vp, _vp, _i, _vp]),
+    "orbx_pyramid_level": (_i, [_vp, _i, _i, _vp, _sz, _ip, _ip]),
+    "orbx_set_profiling": (None, [_vp, _i]),
+    "orbx_get_stage_ms": (_i, [_vp, _vp]),
+    "orbx_debug_blurred_level": (_i, [_vp, _i, _i, _vp, _sz, _ip, _ip]),
+    "orbx_debug_level_candidates": (_i, [_vp, _i, _i, _vp, _i]),
+    "orbx_debug_level_keypoints": (_i, [_vp, _i, _i, _vp, _i]),
+    "orbx_debug_octree_device": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _ip]),
+    "orbm_create": (_i, [C.POINTER(_vp), _i]),
+    "orbm_destroy": (None, [_vp]),
+    "orbm_hamming": (_i, [_vp, _vp]),
+    "orbm_three_maxima": (None, [_vp, _i, _ip, _ip, _ip]),
+    "orbm_match_groups": (_i, [_vp, _vp, _i, _vp, _i, _i] + [_vp] * 8 + [_i, _i, _f, _i, _vp, _vp]),
+    "orbm_match_bruteforce_device": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp, _vp, _vp]),
+    "orbm_match_pairs_device": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _f, _i, _vp, _vp, _vp]),
+    "orbm_match_window": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _f, _f, _f, _f, _i, _i, _f, _i, _vp]),
+}
+# debug hooks that run host builds of the shared host/device cores (no GPU needed)
+HOST_MODEL_SIGNATURES = {
+    "orbx_debug_octree_host": (_i, [_vp, _i, _i, _i, _i, _vp, _ip]),
+    "orbx_debug_std_sort": (None, [_vp, _i, _i]),
+    "orbx_debug_sincos_deg": (None, [_vp, _i, _vp, _vp]),
+}
+
+
+def lib():
+    """Load (building first if needed) liborbx.so."""
+    global _lib
+    if _lib is None:
+        path = _build.build()
+        L = C.CDLL(path)
+        for table in (SIGNATURES, HOST_MODEL_SIGNATURES):
+            for name, (res, args) in table.items():
+                fn = getattr(L, name)  # AttributeError if the library does not export it
+                fn.restype = res
+                fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def last_error():
+    return lib().orbx_last_error().decode()
+
+
+class OrbxError(RuntimeError):
+    pass
+
+
+def check(rc, what):
+    if rc <= -2:
+        raise OrbxError("%s failed (%d): %s" % (what, rc, last_error()))
+    return rc
+
+
+def ptr(a):
+    """void* of a numpy array, a torch tensor (data_ptr) or an int."""
+    if a is None:
+        return None
+    if isinstance(a, int):
+        return C.c_void_p(a)
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data_as(C.c_void_p)
+    return C.c_void_p(a.data_ptr())

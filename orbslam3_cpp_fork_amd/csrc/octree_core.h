@@ -1,0 +1,591 @@
+// octree_core.h -- DistributeOctTree (reference src/ORBextractor.cc:556-753) in array form.
+//
+// The reference keeps a std::list of nodes, each owning a std::vector of keypoints, splits nodes
+// 4-ways with push_front, and in its last phase splits nodes in std::sort order until the list holds
+// N nodes.  Which keypoints survive -- and the order they come out in -- depends on the list order and
+// on how libstdc++'s (unstable) introsort arranges ties.  This file reproduces that behaviour exactly
+// with data structures a GPU workgroup can run:
+//
+//   * the list is an array stored in list order (index 0 = front); one step rebuilds it as
+//        [children of the nodes processed in this step, in reverse push order] ++ [surviving nodes, in order]
+//     which is what erase + push_front produce;
+//   * a node is a rectangle plus a contiguous range [start, start+cnt) of an index array over the
+//     candidates; DivideNode's stable 4-way split of vKeys (:513-526) becomes a stable 4-way partition
+//     of that range, computed for all nodes of a step at once with one prefix scan over the points;
+//   * std::sort (:685) is re-enacted operation for operation (libstdc++ bits/stl_algo.h: introsort with
+//     median-of-3 pivot, threshold 16, final insertion sort; heap-sort fallback included).
+//
+// One source, two builds: the HIP kernel (one workgroup per frame x level; CTX = LDS scans + barriers)
+// and a single-threaded host model (CTX = trivial) that the CPU test-suite checks against the oracle.
+#ifndef ORBX_OCTREE_CORE_H_
+#define ORBX_OCTREE_CORE_H_
+
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define OT_HD __host__ __device__
+#else
+#define OT_HD
+#endif
+
+namespace orbx {
+
+struct OtNode {
+  int x0, x1, y0, y1;  // UL.x, UR.x, UL.y, BR.y (all four corners follow: the nodes are rectangles)
+  int start, cnt;      // range in the point index array
+};
+
+struct Int4 {
+  int v[4];
+};
+
+// Candidate record: x | y << 12 | response << 24, coordinates relative to (minBorderX, minBorderY)
+// exactly as the reference feeds them (src/ORBextractor.cc:842-848).
+OT_HD inline int ot_cx(uint32_t c) { return (int)(c & 0xfffu); }
+OT_HD inline int ot_cy(uint32_t c) { return (int)((c >> 12) & 0xfffu); }
+OT_HD inline int ot_cr(uint32_t c) { return (int)(c >> 24); }
+
+struct OtArgs {
+  // inputs
+  const uint32_t* cand;  // n candidates in feed order
+  int             n;
+  int             W, H;  // maxX - minX, maxY - minY
+  int             N;     // wanted features for this level
+  int             nIni;  // round(W / H), >= 1 (checked by the host)
+  float           hX;    // (float)W / nIni
+  int             maxNodes;
+  // workspace (global memory), sizes: points -> n, nodes -> maxNodes
+  int *               ordA, *ordB, *nodeOfA, *nodeOfB, *P;
+  uint8_t*            qv;
+  OtNode *            nodesA, *nodesB;
+  Int4 *              startCnt, *endCnt;  // per node
+  int *               D, *dIndex, *nCh, *pushOff, *multiOff, *keptRank, *vA, *vB;
+  unsigned long long* sortbuf;  // >= maxNodes entries
+  // outputs
+  uint32_t* outKp;  // kept candidates (same packing), list order
+  int*      outCount;
+};
+
+// ------------------------------------------------------------------------------------------------
+// libstdc++ std::sort re-enactment on 64-bit records; order = (rec >> 16), low 16 bits = payload.
+// ------------------------------------------------------------------------------------------------
+OT_HD inline bool ot_less(unsigned long long a, unsigned long long b) { return (a >> 16) < (b >> 16); }
+
+OT_HD inline void ot_swap(unsigned long long* b, int i, int j) {
+  unsigned long long t = b[i];
+  b[i]                 = b[j];
+  b[j]                 = t;
+}
+
+OT_HD inline void ot_unguarded_linear_insert(unsigned long long* b, int last) {
+  unsigned long long val  = b[last];
+  int                next = last - 1;
+  while (ot_less(val, b[next])) {
+    b[last] = b[next];
+    last    = next;
+    --next;
+  }
+  b[last] = val;
+}
+
+OT_HD inline void ot_insertion_sort(unsigned long long* b, int first, int last) {
+  if (first == last) return;
+  for (int i = first + 1; i != last; ++i) {
+    if (ot_less(b[i], b[first])) {
+      unsigned long long val = b[i];
+      for (int k = i; k > first; --k) b[k] = b[k - 1];  // move_backward(first, i, i + 1)
+      b[first] = val;
+    } else {
+      ot_unguarded_linear_insert(b, i);
+    }
+  }
+}
+
+OT_HD inline void ot_push_heap(unsigned long long* f, int holeIndex, int topIndex, unsigned long long value) {
+  int parent = (holeIndex - 1) / 2;
+  while (holeIndex > topIndex && ot_less(f[parent], value)) {
+    f[holeIndex] = f[parent];
+    holeIndex    = parent;
+    parent       = (holeIndex - 1) / 2;
+  }
+  f[holeIndex] = value;
+}
+
+OT_HD inline void ot_adjust_heap(unsigned long long* f, int holeIndex, int len, unsigned long long value) {
+  const int topIndex    = holeIndex;
+  int       secondChild = holeIndex;
+  while (secondChild < (len - 1) / 2) {
+    secondChild = 2 * (secondChild + 1);
+    if (ot_less(f[secondChild], f[secondChild - 1])) secondChild--;
+    f[holeIndex] = f[secondChild];
+    holeIndex    = secondChild;
+  }
+  if ((len & 1) == 0 && secondChild == (len - 2) / 2) {
+    secondChild  = 2 * (secondChild + 1);
+    f[holeIndex] = f[secondChild - 1];
+    holeIndex    = secondChild - 1;
+  }
+  ot_push_heap(f, holeIndex, topIndex, value);
+}
+
+OT_HD inline void ot_heap_sort(unsigned long long* b, int first, int last) {  // __partial_sort(first, last, last)
+  unsigned long long* f   = b + first;
+  int                 len = last - first;
+  if (len >= 2) {
+    int parent = (len - 2) / 2;
+    while (true) {
+      unsigned long long value = f[parent];
+      ot_adjust_heap(f, parent, len, value);
+      if (parent == 0) break;
+      parent--;
+    }
+  }
+  while (len > 1) {
+    --len;
+    unsigned long long value = f[len];
+    f[len]                   = f[0];
+    ot_adjust_heap(f, 0, len, value);
+  }
+}
+
+OT_HD inline int ot_partition_pivot(unsigned long long* b, int first, int last) {
+  int mid = first + (last - first) / 2;
+  int a = first + 1, bb = mid, c = last - 1;
+  // __move_median_to_first(first, a, b, c)
+  if (ot_less(b[a], b[bb])) {
+    if (ot_less(b[bb], b[c]))
+      ot_swap(b, first, bb);
+    else if (ot_less(b[a], b[c]))
+      ot_swap(b, first, c);
+    else
+      ot_swap(b, first, a);
+  } else if (ot_less(b[a], b[c]))
+    ot_swap(b, first, a);
+  else if (ot_less(b[bb], b[c]))
+    ot_swap(b, first, c);
+  else
+    ot_swap(b, first, bb);
+  // __unguarded_partition(first + 1, last, first)
+  int lo = first + 1, hi = last;
+  while (true) {
+    while (ot_less(b[lo], b[first])) ++lo;
+    --hi;
+    while (ot_less(b[first], b[hi])) --hi;
+    if (!(lo < hi)) return lo;
+    ot_swap(b, lo, hi);
+    ++lo;
+  }
+}
+
+// depth_limit < 0 -> the library's own 2*floor(log2(n)); tests pass small values to reach the heap path.
+OT_HD inline void ot_std_sort(unsigned long long* b, int n, int depth_limit = -1) {
+  if (n <= 0) return;
+  int lg = 0;
+  while ((1 << (lg + 1)) <= n) lg++;
+  int depth0 = depth_limit < 0 ? 2 * lg : depth_limit;
+  // __introsort_loop with an explicit stack (the two sub-ranges are disjoint, order of visiting is free)
+  int sf[64], sl[64], sd[64], sp = 0;
+  sf[0] = 0, sl[0] = n, sd[0] = depth0, sp = 1;
+  while (sp > 0) {
+    --sp;
+    int first = sf[sp], last = sl[sp], depth = sd[sp];
+    while (last - first > 16) {
+      if (depth == 0) {
+        ot_heap_sort(b, first, last);
+        break;
+      }
+      --depth;
+      int cut = ot_partition_pivot(b, first, last);
+      if (sp < 64) {
+        sf[sp] = cut, sl[sp] = last, sd[sp] = depth;
+        sp++;
+      }
+      last = cut;
+    }
+  }
+  // __final_insertion_sort
+  if (n > 16) {
+    ot_insertion_sort(b, 0, 16);
+    for (int i = 16; i < n; ++i) ot_unguarded_linear_insert(b, i);
+  } else {
+    ot_insertion_sort(b, 0, n);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Execution contexts.  A context offers: tid, nt, sync(), scan4() (exclusive scan of one Int4 per
+// thread across the workgroup, returning the grand total too), bcast() and min_reduce().
+// ------------------------------------------------------------------------------------------------
+struct HostCtx {
+  int  tid = 0, nt = 1;
+  void sync() {}
+  Int4 scan4(const Int4& v, Int4* total) {
+    *total = v;
+    Int4 z = {{0, 0, 0, 0}};
+    return z;
+  }
+  int min_reduce(int v) { return v; }
+};
+
+#if defined(__HIPCC__)
+struct DevCtx {
+  int   tid, nt;
+  int*  lds;  // >= 4 * 16 + 4 ints of LDS scratch (per-wave totals)
+  __device__ void sync() { __syncthreads(); }
+  __device__ Int4 scan4(const Int4& v, Int4* total) {
+    const int lane = tid & 63, wave = tid >> 6, nw = (nt + 63) >> 6;
+    Int4      inc  = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        int t = __shfl_up(inc.v[k], off, 64);
+        if (lane >= off) inc.v[k] += t;
+      }
+    }
+    __syncthreads();  // protect lds from a previous use
+    if (lane == 63) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) lds[wave * 4 + k] = inc.v[k];
+    }
+    __syncthreads();
+    Int4 base = {{0, 0, 0, 0}}, tot = {{0, 0, 0, 0}};
+    for (int w = 0; w < nw; w++) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        int t = lds[w * 4 + k];
+        if (w < wave) base.v[k] += t;
+        tot.v[k] += t;
+      }
+    }
+    *total = tot;
+    Int4 ex;
+#pragma unroll
+    for (int k = 0; k < 4; k++) ex.v[k] = base.v[k] + inc.v[k] - v.v[k];
+    return ex;
+  }
+  __device__ int min_reduce(int v) {
+    const int lane = tid & 63, wave = tid >> 6, nw = (nt + 63) >> 6;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off, 64));
+    __syncthreads();
+    if (lane == 0) lds[wave] = v;
+    __syncthreads();
+    int r = lds[0];
+    for (int w = 1; w < nw; w++) r = min(r, lds[w]);
+    return r;
+  }
+};
+#endif
+
+// chunk of [0, n) owned by this thread (contiguous, so that per-thread running counts are prefix counts)
+template <class CTX>
+OT_HD inline void ot_chunk(const CTX& c, int n, int* lo, int* hi) {
+  int per = (n + c.nt - 1) / c.nt;
+  int l   = c.tid * per;
+  int h   = l + per;
+  if (l > n) l = n;
+  if (h > n) h = n;
+  *lo = l;
+  *hi = h;
+}
+
+// Exclusive scan of an int array of length n in place is not needed; what the algorithm needs is
+// "rank of flagged elements": out[i] = number of flagged j < i, plus the total.
+template <class CTX, class F>
+OT_HD inline int ot_rank_flags(CTX& c, int n, F flag, int* out) {
+  int lo, hi;
+  ot_chunk(c, n, &lo, &hi);
+  Int4 loc = {{0, 0, 0, 0}};
+  for (int i = lo; i < hi; i++) loc.v[0] += flag(i) ? 1 : 0;
+  Int4 tot;
+  Int4 ex  = c.scan4(loc, &tot);
+  int  run = ex.v[0];
+  for (int i = lo; i < hi; i++) {
+    out[i] = run;
+    run += flag(i) ? 1 : 0;
+  }
+  c.sync();
+  return tot.v[0];
+}
+
+// ------------------------------------------------------------------------------------------------
+// One "division step": the nodes D[0..nD) of the current list (processing order) are candidates for
+// DivideNode; mode_ordered applies the `size >= N -> break` rule of :722-724.  Returns the new list size.
+// ------------------------------------------------------------------------------------------------
+struct OtState {
+  OtNode* nodes;
+  OtNode* nodesNew;
+  int *   ord, *ordNew, *nodeOf, *nodeOfNew;
+  int *   v, *vNew;
+  int     nNodes;
+  int     nV;  // multi-point children created by the last step (vSizeAndPointerToNode)
+};
+
+template <class CTX>
+OT_HD inline void ot_divide_step(CTX& c, const OtArgs& a, OtState& s, int nD, bool mode_ordered) {
+  const int n = a.n;
+  // -- A: classify every point of a flagged node into its child quadrant, prefix-count per quadrant
+  int lo, hi;
+  ot_chunk(c, n, &lo, &hi);
+  Int4 loc = {{0, 0, 0, 0}};
+  for (int i = lo; i < hi; i++) {
+    const int nd = s.nodeOf[i];
+    int       q  = 4;
+    if (a.dIndex[nd] >= 0) {
+      const OtNode   nn = s.nodes[nd];
+      const uint32_t cd = a.cand[s.ord[i]];
+      const int      mx = nn.x0 + ((nn.x1 - nn.x0 + 1) >> 1);  // UL.x + ceil((UR.x-UL.x)/2)
+      const int      my = nn.y0 + ((nn.y1 - nn.y0 + 1) >> 1);
+      q                 = (ot_cx(cd) < mx ? 0 : 1) + (ot_cy(cd) < my ? 0 : 2);  // n1,n2,n3,n4 = 0,1,2,3
+      loc.v[q]++;
+    }
+    a.qv[i] = (uint8_t)q;
+  }
+  Int4 tot;
+  Int4 run = c.scan4(loc, &tot);
+  for (int i = lo; i < hi; i++) {
+    const int nd = s.nodeOf[i];
+    if (i == 0 || s.nodeOf[i - 1] != nd) {
+      a.startCnt[nd] = run;
+      if (i > 0) a.endCnt[s.nodeOf[i - 1]] = run;
+    }
+    const int q = a.qv[i];
+    if (q < 4) {
+      a.P[i] = run.v[q];
+      run.v[q]++;
+    }
+  }
+  if (hi == n && lo < hi) a.endCnt[s.nodeOf[n - 1]] = run;
+  c.sync();
+  // -- B: per processed node: children / multi-point children; exclusive offsets in processing order
+  int dlo, dhi;
+  ot_chunk(c, nD, &dlo, &dhi);
+  Int4 l2 = {{0, 0, 0, 0}};
+  for (int j = dlo; j < dhi; j++) {
+    const int d  = a.D[j];
+    int       ch = 0, mu = 0;
+    for (int q = 0; q < 4; q++) {
+      int cq = a.endCnt[d].v[q] - a.startCnt[d].v[q];
+      ch += cq > 0;
+      mu += cq > 1;
+    }
+    a.nCh[j] = ch | (mu << 8);
+    l2.v[0] += ch;
+    l2.v[1] += mu;
+  }
+  Int4 t2;
+  Int4 r2 = c.scan4(l2, &t2);
+  for (int j = dlo; j < dhi; j++) {
+    a.pushOff[j]  = r2.v[0];
+    a.multiOff[j] = r2.v[1];
+    r2.v[0] += a.nCh[j] & 0xff;
+    r2.v[1] += a.nCh[j] >> 8;
+  }
+  c.sync();
+  // -- break rule of the ordered phase: stop after the first processed node that brings the list to >= N
+  int K = nD;
+  if (mode_ordered) {
+    int best = nD;
+    for (int j = dlo; j < dhi; j++) {
+      // list size after processing entries 0..j: + children - 1 each
+      int sizeAfter = s.nNodes + (a.pushOff[j] + (a.nCh[j] & 0xff)) - (j + 1);
+      if (sizeAfter >= a.N) {
+        best = j + 1;
+        break;
+      }
+    }
+    K = c.min_reduce(best);
+  }
+  const int Ptot = (K < nD) ? a.pushOff[K] : t2.v[0];
+  const int Mtot = (K < nD) ? a.multiOff[K] : t2.v[1];
+  // -- rank of the surviving nodes
+  const int* dIndex = a.dIndex;
+  ot_rank_flags(c, s.nNodes, [dIndex, K](int i) { return !(dIndex[i] >= 0 && dIndex[i] < K); }, a.keptRank);
+  // -- C: write the new node array
+  for (int j = c.tid; j < K; j += c.nt) {
+    const int    d  = a.D[j];
+    const OtNode nn = s.nodes[d];
+    const int    mx = nn.x0 + ((nn.x1 - nn.x0 + 1) >> 1);
+    const int    my = nn.y0 + ((nn.y1 - nn.y0 + 1) >> 1);
+    const Int4   sc = a.startCnt[d], ec = a.endCnt[d];
+    int          k = 0, m = 0, st = nn.start;
+    Int4         childBase, childIdx;
+    for (int q = 0; q < 4; q++) {
+      const int cq   = ec.v[q] - sc.v[q];
+      childBase.v[q] = st - sc.v[q];
+      childIdx.v[q]  = -1;
+      if (cq > 0) {
+        const int idx = Ptot - 1 - (a.pushOff[j] + k);
+        OtNode    ch;
+        ch.x0 = (q & 1) ? mx : nn.x0;
+        ch.x1 = (q & 1) ? nn.x1 : mx;
+        ch.y0 = (q & 2) ? my : nn.y0;
+        ch.y1 = (q & 2) ? nn.y1 : my;
+        ch.start        = st;
+        ch.cnt          = cq;
+        s.nodesNew[idx] = ch;
+        childIdx.v[q]   = idx;
+        if (cq > 1) {
+          s.vNew[a.multiOff[j] + m] = idx;
+          m++;
+        }
+        k++;
+      }
+      st += cq;
+    }
+    a.startCnt[d] = childBase;  // reused by the point pass below
+    a.endCnt[d]   = childIdx;
+  }
+  for (int i = c.tid; i < s.nNodes; i += c.nt) {
+    const int di = a.dIndex[i];
+    if (!(di >= 0 && di < K)) s.nodesNew[Ptot + a.keptRank[i]] = s.nodes[i];
+  }
+  c.sync();
+  // -- C': move the points (stable within every child), relabel their node
+  for (int i = c.tid; i < n; i += c.nt) {
+    const int nd = s.nodeOf[i];
+    const int di = a.dIndex[nd];
+    if (di >= 0 && di < K) {
+      const int q     = a.qv[i];
+      const int np    = a.startCnt[nd].v[q] + a.P[i];
+      s.ordNew[np]    = s.ord[i];
+      s.nodeOfNew[np] = a.endCnt[nd].v[q];
+    } else {
+      s.ordNew[i]    = s.ord[i];
+      s.nodeOfNew[i] = Ptot + a.keptRank[nd];
+    }
+  }
+  c.sync();
+  const int newSize = Ptot + (s.nNodes - K);
+  // swap ping-pong buffers; clear the flags of the new list
+  {
+    OtNode* tn = s.nodes;
+    s.nodes    = s.nodesNew;
+    s.nodesNew = tn;
+    int* t     = s.ord;
+    s.ord      = s.ordNew;
+    s.ordNew   = t;
+    t          = s.nodeOf;
+    s.nodeOf   = s.nodeOfNew;
+    s.nodeOfNew = t;
+    t          = s.v;
+    s.v        = s.vNew;
+    s.vNew     = t;
+  }
+  s.nNodes = newSize;
+  s.nV     = Mtot;
+  for (int i = c.tid; i < newSize; i += c.nt) a.dIndex[i] = -1;
+  c.sync();
+}
+
+// ------------------------------------------------------------------------------------------------
+// DistributeOctTree
+// ------------------------------------------------------------------------------------------------
+template <class CTX>
+OT_HD inline void ot_distribute(CTX& c, const OtArgs& a) {
+  const int n = a.n;
+  if (n <= 0) {
+    if (c.tid == 0) *a.outCount = 0;
+    c.sync();
+    return;
+  }
+  OtState s;
+  s.nodes = a.nodesA, s.nodesNew = a.nodesB;
+  s.ord = a.ordA, s.ordNew = a.ordB;
+  s.nodeOf = a.nodeOfA, s.nodeOfNew = a.nodeOfB;
+  s.v = a.vA, s.vNew = a.vB;
+  // ---- roots (:566-600): vpIniNodes[kp.pt.x / hX], stable; empty roots erased
+  // counting pass per root keeps the feed order inside each root
+  {
+    int base = 0, nn = 0;
+    for (int r = 0; r < a.nIni; r++) {
+      const uint32_t* cand = a.cand;
+      const float     hX   = a.hX;
+      int cnt = ot_rank_flags(c, n, [cand, hX, r](int i) { return (int)((float)ot_cx(cand[i]) / hX) == r; }, a.P);
+      for (int i = c.tid; i < n; i += c.nt) {
+        if ((int)((float)ot_cx(a.cand[i]) / a.hX) == r) {
+          s.ord[base + a.P[i]]    = i;
+          s.nodeOf[base + a.P[i]] = nn;
+        }
+      }
+      if (cnt > 0) {
+        if (c.tid == 0) {
+          OtNode nd;
+          nd.x0 = (int)(a.hX * (float)r);
+          nd.x1 = (int)(a.hX * (float)(r + 1));
+          nd.y0 = 0;
+          nd.y1 = a.H;
+          nd.start = base;
+          nd.cnt   = cnt;
+          s.nodes[nn] = nd;
+        }
+        nn++;
+      }
+      base += cnt;
+      c.sync();
+    }
+    s.nNodes = nn;
+    for (int i = c.tid; i < nn; i += c.nt) a.dIndex[i] = -1;
+    c.sync();
+  }
+  // ---- main loop (:608-733)
+  bool bFinish = false;
+  while (!bFinish) {
+    const int prevSize = s.nNodes;
+    // sweep: every node that holds more than one point, in list order
+    const OtNode* nodes = s.nodes;
+    int nD = ot_rank_flags(c, s.nNodes, [nodes](int i) { return nodes[i].cnt > 1; }, a.keptRank);
+    for (int i = c.tid; i < s.nNodes; i += c.nt) {
+      if (s.nodes[i].cnt > 1) {
+        a.D[a.keptRank[i]] = i;
+        a.dIndex[i]        = a.keptRank[i];
+      }
+    }
+    c.sync();
+    ot_divide_step(c, a, s, nD, false);
+    const int nToExpand = s.nV;
+    if (s.nNodes >= a.N || s.nNodes == prevSize) {
+      bFinish = true;
+    } else if (s.nNodes + nToExpand * 3 > a.N) {
+      while (!bFinish) {
+        const int prev2 = s.nNodes;
+        const int V     = s.nV;
+        // std::sort(vPrevSizeAndPointerToNode, compareNodes): key (count, UL.x), payload = position in vPrev
+        for (int j = c.tid; j < V; j += c.nt) {
+          const OtNode nd = s.nodes[s.v[j]];
+          a.sortbuf[j]    = ((unsigned long long)(unsigned)nd.cnt << 32) | ((unsigned long long)(unsigned)(nd.x0 & 0xffff) << 16) |
+                         (unsigned long long)(unsigned)j;
+        }
+        c.sync();
+        if (c.tid == 0) ot_std_sort(a.sortbuf, V);
+        c.sync();
+        // processed from the back of the sorted vector (:686)
+        for (int k = c.tid; k < V; k += c.nt) {
+          const int node = s.v[(int)(a.sortbuf[V - 1 - k] & 0xffffu)];
+          a.D[k]         = node;
+          a.dIndex[node] = k;
+        }
+        c.sync();
+        ot_divide_step(c, a, s, V, true);
+        if (s.nNodes >= a.N || s.nNodes == prev2) bFinish = true;
+      }
+    }
+  }
+  // ---- best point per node, first wins on ties, list order (:735-750)
+  for (int i = c.tid; i < s.nNodes; i += c.nt) {
+    const OtNode   nd   = s.nodes[i];
+    uint32_t       best = a.cand[s.ord[nd.start]];
+    for (int k = 1; k < nd.cnt; k++) {
+      const uint32_t cd = a.cand[s.ord[nd.start + k]];
+      if (ot_cr(cd) > ot_cr(best)) best = cd;
+    }
+    a.outKp[i] = best;
+  }
+  if (c.tid == 0) *a.outCount = s.nNodes;
+  c.sync();
+}
+
+}  // namespace orbx
+#endif

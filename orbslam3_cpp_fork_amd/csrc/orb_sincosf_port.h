@@ -20,6 +20,7 @@
 #include <stdint.h>
 
 #if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
 #define ORB_HD __host__ __device__ __forceinline__
 #else
 #define ORB_HD static inline

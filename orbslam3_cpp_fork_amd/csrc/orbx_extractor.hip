@@ -1,0 +1,568 @@
+// orbx_extractor.hip -- host orchestration + C ABI (include/orbx.h) of the ORB front-end on gfx950.
+//
+// One handle owns a HIP stream and a device workspace sized for (image size, batch).  Host-side tables
+// (scale factors, feature quotas, per-level sizes, FAST cell grids, resize index/weight tables) are
+// computed with the reference's exact float/double sequences (src/ORBextractor.cc:403-465, 1140-1150,
+// 755-775; OpenCV resize.cpp) so that every kernel is integer-only where the reference is.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/orbx.h"
+#include "orbx_kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+#define HIP_TRY(expr)                                                                                   \
+  do {                                                                                                  \
+    hipError_t e_ = (expr);                                                                             \
+    if (e_ != hipSuccess) {                                                                             \
+      g_err = std::string(#expr) + ": " + hipGetErrorString(e_);                                        \
+      return -3;                                                                                        \
+    }                                                                                                   \
+  } while (0)
+
+inline int cvRoundF(float v) { return (int)lrintf(v); }
+inline int cvRoundD(double v) { return (int)lrint(v); }
+inline int cvFloorF(float v) {
+  int i = (int)v;
+  return i - (i > v);
+}
+inline int alignUp(int v, int a) { return (v + a - 1) / a * a; }
+
+const signed char kPatternHost[1024] = {
+#include "orb_pattern.inc"
+};
+
+template <class T>
+struct DevBuf {
+  T*     p = nullptr;
+  size_t n = 0;
+  int    ensure(size_t count) {
+    if (count <= n) return 0;
+    if (p) hipFree(p);
+    p = nullptr;
+    n = 0;
+    hipError_t e = hipMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T));
+    if (e != hipSuccess) {
+      g_err = std::string("hipMalloc: ") + hipGetErrorString(e);
+      return -3;
+    }
+    n = count;
+    return 0;
+  }
+  void release() {
+    if (p) hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+};
+
+}  // namespace
+
+struct orbx_extractor {
+  // ---- reference parameters and tables (src/ORBextractor.cc:403-465)
+  int                nfeatures, nlevels, iniTh, minTh;
+  float              scaleFactor;
+  std::vector<float> sf, invSf, sigma2, invSigma2;
+  std::vector<int>   quota;
+  int                device = 0;
+  hipStream_t        stream = nullptr;
+  bool               profiling = false;
+  static constexpr int kProfSlots = 32;  // ring of event sets: one per profiled batch
+  hipEvent_t         ev[kProfSlots][ORBX_NUM_STAGES] = {};
+  bool               evValid = false;
+  int                profCount = 0;  // batches recorded since profiling was enabled
+  // ---- geometry / workspace
+  orbx::FrameGeom geom{};
+  bool            haveGeom = false;
+  int             capB     = 0;
+  int             lastB    = 0;
+  orbx::Bufs      bufs{};
+  DevBuf<uint8_t> dPyr, dBlur, dQv, dStage, dDescOut;
+  DevBuf<int2>    dXtab, dYtab;
+  DevBuf<int>     dCellSlot, dCellCount, dOrdA, dOrdB, dNodeOfA, dNodeOfB, dP, dD, dDIndex, dNCh, dPushOff, dMultiOff, dKeptRank, dVA,
+      dVB, dCandCount, dLvlCount, dOutIdx, dCounts;
+  DevBuf<uint32_t>           dSlots, dCand, dLvlKp;
+  DevBuf<orbx::OtNode>       dNodesA, dNodesB;
+  DevBuf<orbx::Int4>         dStartCnt, dEndCnt;
+  DevBuf<unsigned long long> dSortbuf;
+  DevBuf<orbx::PatternTab>   dPattern;
+  DevBuf<orbx::KpRec>        dKpOut;
+  int                        stagePitch = 0;
+
+  int makeGeometry(int rows, int cols);
+  int ensureWorkspace(int rows, int cols, int B);
+  int run(const uint8_t* d_imgs, int B, int rows, int cols, size_t step, size_t frameStride, int lap0, int lap1, orbx::KpRec* d_kps,
+          uint8_t* d_desc, int* d_counts, int cap, hipStream_t s);
+};
+
+// Level sizes, FAST grids, quadtree roots, buffer offsets and resize tables for one image size.
+int orbx_extractor::makeGeometry(int rows, int cols) {
+  using namespace orbx;
+  if (haveGeom && geom.rows == rows && geom.cols == cols) return 0;
+  if (rows <= 0 || cols <= 0) return -1;
+  if (cols > 4000 || rows > 4000) {
+    g_err = "image larger than 4000 px is not supported (12-bit candidate coordinates)";
+    return -2;
+  }
+  FrameGeom g{};
+  g.nlevels = nlevels;
+  g.rows = rows, g.cols = cols;
+  std::vector<int2> xt, yt;
+  std::vector<int>  cellSlot;
+  int               pyrOff = 0, blurOff = 0, cellBase = 0, slotBase = 0, nodeBase = 0, kpBase = 0, tileBase = 0;
+  for (int l = 0; l < nlevels; l++) {
+    LevelGeom& L = g.lv[l];
+    L.w = cvRoundF((float)cols * invSf[l]);  // src/ORBextractor.cc:1142-1143
+    L.h = cvRoundF((float)rows * invSf[l]);
+    if (L.w < 2 * kMinBorder + 35 || L.h < 2 * kMinBorder + 35) {
+      g_err = "image too small for the pyramid depth: a level has less than one 35-px FAST cell";
+      return -2;
+    }
+    L.pitch = alignUp(L.w, 64);
+    L.pyrOff = pyrOff;
+    if (l > 0) pyrOff += L.pitch * alignUp(L.h, 4);
+    L.blurPitch = alignUp(L.w, 64);
+    L.blurOff   = blurOff;
+    blurOff += L.blurPitch * alignUp(L.h, 4);
+    // FAST grid (src/ORBextractor.cc:761-775)
+    L.maxBX            = L.w - kEdgeThreshold + 3;
+    L.maxBY            = L.h - kEdgeThreshold + 3;
+    const float width  = (float)(L.maxBX - kMinBorder);
+    const float height = (float)(L.maxBY - kMinBorder);
+    const float W      = 35;
+    L.nCols            = (int)(width / W);
+    L.nRows            = (int)(height / W);
+    L.wCell            = (int)std::ceil(width / L.nCols);
+    L.hCell            = (int)std::ceil(height / L.nRows);
+    if (L.wCell + 6 > kFastTileMax || L.hCell + 6 > kFastTileMax) {
+      g_err = "FAST cell larger than the kernel tile";
+      return -2;
+    }
+    L.cellBase = cellBase;
+    L.slotBase = slotBase;
+    int slots = 0;
+    for (int i = 0; i < L.nRows; i++)
+      for (int j = 0; j < L.nCols; j++) {
+        const int iniY = kMinBorder + i * L.hCell, iniX = kMinBorder + j * L.wCell;
+        int       capc = 0;
+        if (!(iniY >= L.maxBY - 3 || iniX >= L.maxBX - 6)) {
+          const int maxY = std::min(iniY + L.hCell + 6, L.maxBY), maxX = std::min(iniX + L.wCell + 6, L.maxBX);
+          const int iw = maxX - iniX - 6, ih = maxY - iniY - 6;
+          // strict 3x3 NMS: no two keypoints are 8-neighbours -> at most one per 2x2 block
+          if (iw > 0 && ih > 0) capc = ((iw + 1) / 2) * ((ih + 1) / 2);
+        }
+        cellSlot.push_back(slots);
+        slots += capc;
+      }
+    const int nc = L.nCols * L.nRows;
+    L.slotCount  = alignUp(std::max(slots, nc) + 16, 16);
+    cellBase += nc;
+    slotBase += L.slotCount;
+    // quadtree (src/ORBextractor.cc:566-570)
+    L.N    = quota[l];
+    L.nIni = (int)std::round(width / height);
+    if (L.nIni <= 0) {
+      g_err = "portrait image with height > 2 x width: DistributeOctTree would divide by zero (nIni == 0)";
+      return -2;
+    }
+    L.hX       = width / L.nIni;
+    L.nodeCap  = alignUp(std::max(L.N + 3, 4 * L.nIni) + 16, 16);
+    L.nodeBase = nodeBase;
+    nodeBase += L.nodeCap;
+    L.kpCap  = std::max(L.N + 3, 4 * L.nIni);
+    L.kpBase = kpBase;
+    kpBase += L.kpCap;
+    L.scale     = sf[l];
+    L.patchSize = (int)(kPatchSize * sf[l]);  // src/ORBextractor.cc:865
+    // blur tiles
+    L.blurTilesX   = (L.w + kBlurTileW - 1) / kBlurTileW;
+    L.blurTilesY   = (L.h + kBlurTileH - 1) / kBlurTileH;
+    L.blurTileBase = tileBase;
+    tileBase += L.blurTilesX * L.blurTilesY;
+    // cv::resize INTER_LINEAR tables (OpenCV resize.cpp)
+    L.xtabOff = (int)xt.size();
+    L.ytabOff = (int)yt.size();
+    if (l > 0) {
+      const int    sw = g.lv[l - 1].w, sh = g.lv[l - 1].h;
+      const double scale_x = 1. / ((double)L.w / sw), scale_y = 1. / ((double)L.h / sh);
+      auto         q11 = [](float v) { return (int)(short)std::min(std::max(cvRoundF(v * 2048), -32768), 32767); };
+      for (int dx = 0; dx < L.w; dx++) {
+        float fx = (float)((dx + 0.5) * scale_x - 0.5);
+        int   sx = cvFloorF(fx);
+        fx -= sx;
+        if (sx < 0) fx = 0, sx = 0;
+        if (sx >= sw - 1) fx = 0, sx = sw - 1;
+        xt.push_back(make_int2(sx, (q11(1.f - fx) & 0xffff) | (q11(fx) << 16)));
+      }
+      for (int dy = 0; dy < L.h; dy++) {
+        float fy = (float)((dy + 0.5) * scale_y - 0.5);
+        int   sy = cvFloorF(fy);
+        fy -= sy;
+        yt.push_back(make_int2(sy, (q11(1.f - fy) & 0xffff) | (q11(fy) << 16)));
+      }
+    }
+  }
+  g.totalCells     = cellBase;
+  g.totalSlots     = slotBase;
+  g.totalNodes     = nodeBase;
+  g.totalKp        = kpBase;
+  g.totalBlurTiles = tileBase;
+  g.pyrBytes       = alignUp(pyrOff, 256);
+  g.blurBytes      = alignUp(blurOff, 256);
+  // upload tables
+  if (dXtab.ensure(xt.size() + 1) || dYtab.ensure(yt.size() + 1) || dCellSlot.ensure(cellSlot.size() + 1)) return -3;
+  HIP_TRY(hipMemcpy(dXtab.p, xt.data(), xt.size() * sizeof(int2), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(dYtab.p, yt.data(), yt.size() * sizeof(int2), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(dCellSlot.p, cellSlot.data(), cellSlot.size() * sizeof(int), hipMemcpyHostToDevice));
+  geom     = g;
+  haveGeom = true;
+  capB     = 0;  // workspace must be re-laid out
+  return 0;
+}
+
+int orbx_extractor::ensureWorkspace(int rows, int cols, int B) {
+  int rc = makeGeometry(rows, cols);
+  if (rc) return rc;
+  if (B <= capB) return 0;
+  const orbx::FrameGeom& g  = geom;
+  const size_t           nb = (size_t)B;
+  const size_t           np = nb * g.totalSlots, nn = nb * g.totalNodes;
+  if (dPyr.ensure(nb * g.pyrBytes) || dBlur.ensure(nb * g.blurBytes) || dSlots.ensure(np) || dCellCount.ensure(nb * g.totalCells) ||
+      dCand.ensure(np) || dOrdA.ensure(np) || dOrdB.ensure(np) || dNodeOfA.ensure(np) || dNodeOfB.ensure(np) || dP.ensure(np) ||
+      dQv.ensure(np) || dNodesA.ensure(nn) || dNodesB.ensure(nn) || dStartCnt.ensure(nn) || dEndCnt.ensure(nn) || dD.ensure(nn) ||
+      dDIndex.ensure(nn) || dNCh.ensure(nn) || dPushOff.ensure(nn) || dMultiOff.ensure(nn) || dKeptRank.ensure(nn) || dVA.ensure(nn) ||
+      dVB.ensure(nn) || dSortbuf.ensure(nn) || dCandCount.ensure(nb * g.nlevels) || dLvlKp.ensure(nb * g.totalKp) ||
+      dLvlCount.ensure(nb * g.nlevels) || dOutIdx.ensure(nb * g.totalKp))
+    return -3;
+  orbx::Bufs& b = bufs;
+  b.pyr = dPyr.p, b.blur = dBlur.p, b.xtab = dXtab.p, b.ytab = dYtab.p, b.cellSlot = dCellSlot.p, b.slots = dSlots.p;
+  b.cellCount = dCellCount.p, b.cand = dCand.p, b.ordA = dOrdA.p, b.ordB = dOrdB.p, b.nodeOfA = dNodeOfA.p, b.nodeOfB = dNodeOfB.p;
+  b.P = dP.p, b.qv = dQv.p, b.nodesA = dNodesA.p, b.nodesB = dNodesB.p, b.startCnt = dStartCnt.p, b.endCnt = dEndCnt.p, b.D = dD.p;
+  b.dIndex = dDIndex.p, b.nCh = dNCh.p, b.pushOff = dPushOff.p, b.multiOff = dMultiOff.p, b.keptRank = dKeptRank.p, b.vA = dVA.p;
+  b.vB = dVB.p, b.sortbuf = dSortbuf.p, b.candCount = dCandCount.p, b.lvlKp = dLvlKp.p, b.lvlCount = dLvlCount.p, b.outIdx = dOutIdx.p;
+  capB = B;
+  return 0;
+}
+
+int orbx_extractor::run(const uint8_t* d_imgs, int B, int rows, int cols, size_t step, size_t frameStride, int lap0, int lap1,
+                        orbx::KpRec* d_kps, uint8_t* d_desc, int* d_counts, int cap, hipStream_t s) {
+  using namespace orbx;
+  int rc = ensureWorkspace(rows, cols, B);
+  if (rc) return rc;
+  const FrameGeom& g = geom;
+  Bufs             b = bufs;
+  b.img0            = d_imgs;
+  b.img0FrameStride = (long long)frameStride;
+  b.img0Pitch       = (int)step;
+  bufs              = b;  // remembered for the pyramid / debug accessors
+  lastB             = B;
+  const bool prof   = profiling;
+  if (prof && !evValid) {
+    for (auto& slot : ev)
+      for (auto& e : slot) HIP_TRY(hipEventCreate(&e));
+    evValid = true;
+  }
+  hipEvent_t* ev = this->ev[profCount % kProfSlots];
+  if (prof) HIP_TRY(hipEventRecord(ev[0], s));
+  for (int l = 1; l < g.nlevels; l++) {
+    dim3 grid((g.lv[l].w + 255) / 256, (g.lv[l].h + 3) / 4, B), block(64, 4, 1);
+    hipLaunchKernelGGL(k_resize_level, grid, block, 0, s, b, g, l);
+  }
+  if (prof) HIP_TRY(hipEventRecord(ev[1], s));
+  hipLaunchKernelGGL(k_fast_cells, dim3(g.totalCells, B), dim3(256), 0, s, b, g, std::min(std::max(iniTh, 0), 255),
+                     std::min(std::max(minTh, 0), 255));
+  if (prof) HIP_TRY(hipEventRecord(ev[2], s));
+  hipLaunchKernelGGL(k_octree, dim3(g.nlevels, B), dim3(kOctThreads), 0, s, b, g);
+  if (prof) HIP_TRY(hipEventRecord(ev[3], s));
+  hipLaunchKernelGGL(k_layout, dim3(B), dim3(256), 0, s, b, g, lap0, lap1, d_counts, cap);
+  if (prof) HIP_TRY(hipEventRecord(ev[4], s));
+  hipLaunchKernelGGL(k_blur_levels, dim3(g.totalBlurTiles, B), dim3(256), 0, s, b, g);
+  if (prof) HIP_TRY(hipEventRecord(ev[5], s));
+  hipLaunchKernelGGL(k_orient_describe, dim3((g.totalKp + 3) / 4, B), dim3(256), 0, s, b, g, dPattern.p, d_counts, d_kps, d_desc, cap);
+  if (prof) {
+    HIP_TRY(hipEventRecord(ev[6], s));
+    profCount++;
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" {
+
+const char* orbx_last_error(void) { return g_err.c_str(); }
+
+int orbx_create(orbx_t** out, int nfeatures, float scale_factor, int nlevels, int ini_th_fast, int min_th_fast, int device_id) {
+  if (!out) return -2;
+  *out = nullptr;
+  if (nfeatures < 1 || nlevels < 1 || nlevels > orbx::kMaxLevels || !(scale_factor > 1.0f) || min_th_fast > ini_th_fast) {
+    g_err = "orbx_create: bad parameters";
+    return -2;
+  }
+  HIP_TRY(hipSetDevice(device_id));
+  orbx_extractor* h = new orbx_extractor();
+  h->nfeatures = nfeatures, h->nlevels = nlevels, h->iniTh = ini_th_fast, h->minTh = min_th_fast, h->scaleFactor = scale_factor;
+  h->device = device_id;
+  // src/ORBextractor.cc:409-440, exact float sequence
+  h->sf.resize(nlevels), h->sigma2.resize(nlevels), h->invSf.resize(nlevels), h->invSigma2.resize(nlevels), h->quota.resize(nlevels);
+  h->sf[0] = 1.0f, h->sigma2[0] = 1.0f;
+  for (int i = 1; i < nlevels; i++) {
+    h->sf[i]     = h->sf[i - 1] * scale_factor;
+    h->sigma2[i] = h->sf[i] * h->sf[i];
+  }
+  for (int i = 0; i < nlevels; i++) {
+    h->invSf[i]     = 1.0f / h->sf[i];
+    h->invSigma2[i] = 1.0f / h->sigma2[i];
+  }
+  float factor                   = 1.0f / scale_factor;
+  float nDesiredFeaturesPerScale = nfeatures * (1 - factor) / (1 - (float)std::pow((double)factor, (double)nlevels));
+  int   sumFeatures              = 0;
+  for (int level = 0; level < nlevels - 1; level++) {
+    h->quota[level] = cvRoundF(nDesiredFeaturesPerScale);
+    sumFeatures += h->quota[level];
+    nDesiredFeaturesPerScale *= factor;
+  }
+  h->quota[nlevels - 1] = std::max(nfeatures - sumFeatures, 0);
+  hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    g_err = std::string("hipStreamCreate: ") + hipGetErrorString(e);
+    delete h;
+    return -3;
+  }
+  if (h->dPattern.ensure(1)) {
+    delete h;
+    return -3;
+  }
+  e = hipMemcpy(h->dPattern.p, kPatternHost, 1024, hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    g_err = std::string("hipMemcpy(pattern): ") + hipGetErrorString(e);
+    delete h;
+    return -3;
+  }
+  *out = h;
+  return 0;
+}
+
+void orbx_destroy(orbx_t* h) {
+  if (!h) return;
+  hipSetDevice(h->device);
+  if (h->stream) {
+    hipStreamSynchronize(h->stream);
+    hipStreamDestroy(h->stream);
+  }
+  if (h->evValid)
+    for (auto& slot : h->ev)
+      for (auto& e : slot) hipEventDestroy(e);
+  h->dPyr.release(), h->dBlur.release(), h->dQv.release(), h->dStage.release(), h->dDescOut.release(), h->dXtab.release(), h->dYtab.release();
+  h->dCellSlot.release(), h->dCellCount.release(), h->dOrdA.release(), h->dOrdB.release(), h->dNodeOfA.release(), h->dNodeOfB.release();
+  h->dP.release(), h->dD.release(), h->dDIndex.release(), h->dNCh.release(), h->dPushOff.release(), h->dMultiOff.release();
+  h->dKeptRank.release(), h->dVA.release(), h->dVB.release(), h->dCandCount.release(), h->dLvlCount.release(), h->dOutIdx.release();
+  h->dCounts.release(), h->dSlots.release(), h->dCand.release(), h->dLvlKp.release(), h->dNodesA.release(), h->dNodesB.release();
+  h->dStartCnt.release(), h->dEndCnt.release(), h->dSortbuf.release(), h->dPattern.release(), h->dKpOut.release();
+  delete h;
+}
+
+int orbx_get_levels(const orbx_t* h) { return h->nlevels; }
+
+void orbx_get_scale_tables(const orbx_t* h, float* scale, float* inv_scale, float* sigma2, float* inv_sigma2) {
+  for (int i = 0; i < h->nlevels; i++) {
+    if (scale) scale[i] = h->sf[i];
+    if (inv_scale) inv_scale[i] = h->invSf[i];
+    if (sigma2) sigma2[i] = h->sigma2[i];
+    if (inv_sigma2) inv_sigma2[i] = h->invSigma2[i];
+  }
+}
+
+void orbx_get_features_per_level(const orbx_t* h, int* out) {
+  for (int i = 0; i < h->nlevels; i++) out[i] = h->quota[i];
+}
+
+int orbx_max_keypoints(orbx_t* h, int rows, int cols) {
+  if (!h) return -2;
+  hipSetDevice(h->device);
+  int rc = h->makeGeometry(rows, cols);
+  if (rc) return rc < 0 ? rc : -2;
+  return h->geom.totalKp;
+}
+
+int orbx_extract_batch_device(orbx_t* h, const uint8_t* d_imgs, int nframes, int rows, int cols, size_t step_bytes,
+                              size_t frame_stride_bytes, int lap0, int lap1, orbx_keypoint_t* d_kps, uint8_t* d_desc, int* d_counts,
+                              int cap, void* stream) {
+  if (!h || !d_kps || !d_desc || !d_counts || nframes < 0) {
+    g_err = "orbx_extract_batch_device: null argument";
+    return -2;
+  }
+  if (!d_imgs || rows <= 0 || cols <= 0 || nframes == 0) return -1;
+  if (step_bytes < (size_t)cols) {
+    g_err = "step_bytes < cols";
+    return -2;
+  }
+  HIP_TRY(hipSetDevice(h->device));
+  int rc = h->makeGeometry(rows, cols);
+  if (rc) return rc;
+  if (cap < h->geom.totalKp) {
+    g_err = "output capacity below orbx_max_keypoints()";
+    return -2;
+  }
+  hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+  return h->run(d_imgs, nframes, rows, cols, step_bytes, frame_stride_bytes, lap0, lap1, (orbx::KpRec*)d_kps, d_desc, d_counts, cap, s);
+}
+
+int orbx_extract(orbx_t* h, const uint8_t* img, int rows, int cols, size_t step_bytes, int lap0, int lap1, orbx_keypoint_t* kps,
+                 uint8_t* desc, int cap, int* n_out) {
+  if (n_out) *n_out = 0;
+  if (!h) return -2;
+  if (!img || rows <= 0 || cols <= 0) return -1;  // _image.empty() (src/ORBextractor.cc:1060-1062)
+  if (!kps || !desc || step_bytes < (size_t)cols) {
+    g_err = "orbx_extract: bad arguments";
+    return -2;
+  }
+  HIP_TRY(hipSetDevice(h->device));
+  int rc = h->makeGeometry(rows, cols);
+  if (rc) return rc;
+  const int need = h->geom.totalKp;
+  if (cap < need) {
+    g_err = "orbx_extract: cap below orbx_max_keypoints()";
+    return -2;
+  }
+  const int pitch = alignUp(cols, 64);
+  if (h->dStage.ensure((size_t)pitch * rows) || h->dKpOut.ensure(need) || h->dDescOut.ensure((size_t)need * 32) || h->dCounts.ensure(2))
+    return -3;
+  HIP_TRY(hipMemcpy2DAsync(h->dStage.p, pitch, img, step_bytes, cols, rows, hipMemcpyHostToDevice, h->stream));
+  rc = h->run(h->dStage.p, 1, rows, cols, pitch, (size_t)pitch * rows, lap0, lap1, h->dKpOut.p, h->dDescOut.p, h->dCounts.p, need, h->stream);
+  if (rc) return rc;
+  int counts[2] = {0, 0};
+  HIP_TRY(hipMemcpyAsync(counts, h->dCounts.p, sizeof(counts), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  const int n = counts[0];
+  if (n > 0) {
+    HIP_TRY(hipMemcpy(kps, h->dKpOut.p, (size_t)n * sizeof(orbx_keypoint_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(desc, h->dDescOut.p, (size_t)n * 32, hipMemcpyDeviceToHost));
+  }
+  if (n_out) *n_out = n;
+  return counts[1];
+}
+
+static int copy_level(orbx_t* h, const uint8_t* base, int pitch, int w, int hgt, uint8_t* dst, size_t dst_step, int* rows, int* cols) {
+  if (rows) *rows = hgt;
+  if (cols) *cols = w;
+  if (!dst) return 0;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipMemcpy2D(dst, dst_step, base, pitch, w, hgt, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int orbx_pyramid_level(orbx_t* h, int frame, int level, uint8_t* dst, size_t dst_step, int* rows, int* cols) {
+  if (!h || !h->haveGeom || level < 0 || level >= h->nlevels || frame < 0 || frame >= h->lastB) return -2;
+  HIP_TRY(hipSetDevice(h->device));
+  const orbx::LevelGeom& L = h->geom.lv[level];
+  if (level == 0)
+    return copy_level(h, h->bufs.img0 + (long long)frame * h->bufs.img0FrameStride, h->bufs.img0Pitch, L.w, L.h, dst, dst_step, rows, cols);
+  return copy_level(h, h->bufs.pyr + (long long)frame * h->geom.pyrBytes + L.pyrOff, L.pitch, L.w, L.h, dst, dst_step, rows, cols);
+}
+
+int orbx_debug_blurred_level(orbx_t* h, int frame, int level, uint8_t* dst, size_t dst_step, int* rows, int* cols) {
+  if (!h || !h->haveGeom || level < 0 || level >= h->nlevels || frame < 0 || frame >= h->lastB) return -2;
+  HIP_TRY(hipSetDevice(h->device));
+  const orbx::LevelGeom& L = h->geom.lv[level];
+  return copy_level(h, h->bufs.blur + (long long)frame * h->geom.blurBytes + L.blurOff, L.blurPitch, L.w, L.h, dst, dst_step, rows, cols);
+}
+
+static int copy_counted(orbx_t* h, const int* d_count, const uint32_t* d_src, uint32_t* out, int cap) {
+  int n = 0;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipMemcpy(&n, d_count, sizeof(int), hipMemcpyDeviceToHost));
+  if (out && n > 0) HIP_TRY(hipMemcpy(out, d_src, (size_t)std::min(n, cap) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  return n;
+}
+
+int orbx_debug_level_candidates(orbx_t* h, int frame, int level, uint32_t* out, int cap) {
+  if (!h || !h->haveGeom || level < 0 || level >= h->nlevels || frame < 0 || frame >= h->lastB) return -2;
+  HIP_TRY(hipSetDevice(h->device));
+  const orbx::FrameGeom& g = h->geom;
+  return copy_counted(h, h->bufs.candCount + (long long)frame * g.nlevels + level,
+                      h->bufs.cand + (long long)frame * g.totalSlots + g.lv[level].slotBase, out, cap);
+}
+
+int orbx_debug_level_keypoints(orbx_t* h, int frame, int level, uint32_t* out, int cap) {
+  if (!h || !h->haveGeom || level < 0 || level >= h->nlevels || frame < 0 || frame >= h->lastB) return -2;
+  HIP_TRY(hipSetDevice(h->device));
+  const orbx::FrameGeom& g = h->geom;
+  return copy_counted(h, h->bufs.lvlCount + (long long)frame * g.nlevels + level,
+                      h->bufs.lvlKp + (long long)frame * g.totalKp + g.lv[level].kpBase, out, cap);
+}
+
+int orbx_debug_octree_device(orbx_t* h, const uint32_t* cand, int n, int W, int H, int N, uint32_t* out, int* out_count) {
+  using namespace orbx;
+  if (!h || n < 0 || W <= 0 || H <= 0 || N < 0) return -2;
+  HIP_TRY(hipSetDevice(h->device));
+  const int nIni = (int)std::round((float)W / (float)H);
+  if (nIni <= 0) return -2;
+  const int    maxNodes = alignUp(std::max(N + 3, 4 * nIni) + 16, 16);
+  const size_t np = (size_t)n + 16, nn = (size_t)maxNodes;
+  DevBuf<uint32_t>           dc, dout;
+  DevBuf<int>                ordA, ordB, nA, nB, P, D, dI, nCh, pO, mO, kR, vA, vB, cnt;
+  DevBuf<uint8_t>            qv;
+  DevBuf<OtNode>             nodesA, nodesB;
+  DevBuf<Int4>               sc, ec;
+  DevBuf<unsigned long long> sb;
+  if (dc.ensure(np) || dout.ensure(nn) || ordA.ensure(np) || ordB.ensure(np) || nA.ensure(np) || nB.ensure(np) || P.ensure(np) ||
+      qv.ensure(np) || nodesA.ensure(nn) || nodesB.ensure(nn) || sc.ensure(nn) || ec.ensure(nn) || D.ensure(nn) || dI.ensure(nn) ||
+      nCh.ensure(nn) || pO.ensure(nn) || mO.ensure(nn) || kR.ensure(nn) || vA.ensure(nn) || vB.ensure(nn) || sb.ensure(nn) || cnt.ensure(1))
+    return -3;
+  if (n > 0) HIP_TRY(hipMemcpy(dc.p, cand, (size_t)n * 4, hipMemcpyHostToDevice));
+  OtArgs a;
+  memset(&a, 0, sizeof(a));
+  a.cand = dc.p, a.n = n, a.W = W, a.H = H, a.N = N, a.nIni = nIni, a.hX = (float)W / nIni, a.maxNodes = maxNodes;
+  a.ordA = ordA.p, a.ordB = ordB.p, a.nodeOfA = nA.p, a.nodeOfB = nB.p, a.P = P.p, a.qv = qv.p, a.nodesA = nodesA.p, a.nodesB = nodesB.p;
+  a.startCnt = sc.p, a.endCnt = ec.p, a.D = D.p, a.dIndex = dI.p, a.nCh = nCh.p, a.pushOff = pO.p, a.multiOff = mO.p, a.keptRank = kR.p;
+  a.vA = vA.p, a.vB = vB.p, a.sortbuf = sb.p, a.outKp = dout.p, a.outCount = cnt.p;
+  hipLaunchKernelGGL(k_octree_only, dim3(1), dim3(kOctThreads), 0, h->stream, a);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  int c = 0;
+  HIP_TRY(hipMemcpy(&c, cnt.p, sizeof(int), hipMemcpyDeviceToHost));
+  if (c > 0) HIP_TRY(hipMemcpy(out, dout.p, (size_t)c * 4, hipMemcpyDeviceToHost));
+  if (out_count) *out_count = c;
+  dc.release(), dout.release(), ordA.release(), ordB.release(), nA.release(), nB.release(), P.release(), D.release(), dI.release();
+  nCh.release(), pO.release(), mO.release(), kR.release(), vA.release(), vB.release(), cnt.release(), qv.release(), nodesA.release();
+  nodesB.release(), sc.release(), ec.release(), sb.release();
+  return 0;
+}
+
+void orbx_set_profiling(orbx_t* h, int enable) {
+  if (!h) return;
+  h->profiling = enable != 0;
+  h->profCount = 0;
+}
+
+// Mean over the batches recorded since orbx_set_profiling(h, 1) (at most the last 32); returns how many.
+int orbx_get_stage_ms(orbx_t* h, float* ms) {
+  if (!h || !ms || !h->evValid || h->profCount == 0) return -2;
+  HIP_TRY(hipSetDevice(h->device));
+  const int nrec = std::min(h->profCount, orbx_extractor::kProfSlots);
+  for (int i = 0; i < ORBX_NUM_STAGES; i++) ms[i] = 0.f;
+  for (int r = 0; r < nrec; r++) {
+    hipEvent_t* ev = h->ev[r];
+    HIP_TRY(hipEventSynchronize(ev[ORBX_NUM_STAGES - 1]));
+    float t;
+    for (int i = 0; i < ORBX_NUM_STAGES - 1; i++) {
+      HIP_TRY(hipEventElapsedTime(&t, ev[i], ev[i + 1]));
+      ms[i] += t;
+    }
+    HIP_TRY(hipEventElapsedTime(&t, ev[0], ev[ORBX_NUM_STAGES - 1]));
+    ms[ORBX_NUM_STAGES - 1] += t;
+  }
+  for (int i = 0; i < ORBX_NUM_STAGES; i++) ms[i] /= nrec;
+  return nrec;
+}
+
+}  // extern "C"

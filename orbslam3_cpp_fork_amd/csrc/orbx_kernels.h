@@ -1,0 +1,561 @@
+// orbx_kernels.h -- gfx950 kernels of the ORB front-end.  Included once by orbx_extractor.hip.
+//
+// Stage map (reference function -> kernel):
+//   ComputePyramid            src/ORBextractor.cc:1140-1173 -> k_resize_level   (one launch per level >= 1)
+//   cv::FAST per cell         :800-839                      -> k_fast_cells     (one workgroup per cell)
+//   DistributeOctTree         :556-753                      -> k_octree         (one workgroup per frame x level)
+//   operator() output order   :1115-1134                    -> k_layout         (one workgroup per frame)
+//   cv::GaussianBlur 7x7      :1103-1104                    -> k_blur_levels    (64x16 tiles, all levels)
+//   IC_Angle + rBRIEF + emit  :66-139, :1120-1132           -> k_orient_describe (one wave per keypoint)
+// All arithmetic is integer except fastAtan2, the tap rotation and pt *= scale, which follow the
+// reference's float sequence (compile with -ffp-contract=off).
+#ifndef ORBX_KERNELS_H_
+#define ORBX_KERNELS_H_
+
+#include <hip/hip_runtime.h>
+
+#include "octree_core.h"
+#include "orb_sincosf_port.h"
+#include "orbx_geom.h"
+
+namespace orbx {
+
+struct KpRec {  // == orbx_keypoint_t
+  float x, y, size, angle, response;
+  int   octave, class_id;
+};
+
+struct Bufs {
+  // level 0 of every frame is the caller's image itself
+  const uint8_t* img0;
+  long long      img0FrameStride;
+  int            img0Pitch;
+  uint8_t*       pyr;   // [B][pyrBytes]   levels >= 1
+  uint8_t*       blur;  // [B][blurBytes]  all levels
+  const int2*    xtab;  // resize tables: .x = source index, .y = a0 | a1 << 16 (Q11)
+  const int2*    ytab;
+  const int*     cellSlot;   // [totalCells] slot base of each cell inside the frame's slot array
+  uint32_t*      slots;      // [B][totalSlots] per-cell candidate slots written by FAST
+  int*           cellCount;  // [B][totalCells]
+  // quadtree workspace, per frame: point arrays [totalSlots], node arrays [totalNodes]
+  uint32_t*           cand;
+  int *               ordA, *ordB, *nodeOfA, *nodeOfB, *P;
+  uint8_t*            qv;
+  OtNode *            nodesA, *nodesB;
+  Int4 *              startCnt, *endCnt;
+  int *               D, *dIndex, *nCh, *pushOff, *multiOff, *keptRank, *vA, *vB;
+  unsigned long long* sortbuf;
+  int*                candCount;  // [B][L]
+  uint32_t*           lvlKp;      // [B][totalKp]
+  int*                lvlCount;   // [B][L]
+  int*                outIdx;     // [B][totalKp]
+};
+
+__device__ __forceinline__ const uint8_t* level_raw(const Bufs& b, const FrameGeom& g, int level, int f, int* pitch) {
+  if (level == 0) {
+    *pitch = b.img0Pitch;
+    return b.img0 + (long long)f * b.img0FrameStride;
+  }
+  *pitch = g.lv[level].pitch;
+  return b.pyr + (long long)f * g.pyrBytes + g.lv[level].pyrOff;
+}
+
+// ------------------------------------------------------------------------------------------------
+// ComputePyramid: cv::resize(INTER_LINEAR) 8UC1 fixed point (OpenCV resize.cpp).
+// Tables (source index + Q11 weights) are built on the host with the exact float/double recipe, so
+// the kernel is integer-only.  Thread = 4 adjacent destination pixels, one 32-bit store.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_resize_level(Bufs b, FrameGeom g, int level) {
+  const LevelGeom& L  = g.lv[level];
+  const LevelGeom& Ls = g.lv[level - 1];
+  const int        f  = blockIdx.z;
+  const int        dx = (blockIdx.x * 64 + threadIdx.x) * 4;
+  const int        dy = blockIdx.y * 4 + threadIdx.y;
+  if (dx >= L.w || dy >= L.h) return;
+  int            sp;
+  const uint8_t* S   = level_raw(b, g, level - 1, f, &sp);
+  uint8_t*       D   = b.pyr + (long long)f * g.pyrBytes + L.pyrOff + (long long)dy * L.pitch;
+  const int2     yt  = b.ytab[L.ytabOff + dy];
+  const int      sy0 = min(max(yt.x, 0), Ls.h - 1), sy1 = min(max(yt.x + 1, 0), Ls.h - 1);
+  const int      b0 = (short)(yt.y & 0xffff), b1 = yt.y >> 16;
+  const uint8_t *S0 = S + (long long)sy0 * sp, *S1 = S + (long long)sy1 * sp;
+  uint32_t       out = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    int x = dx + k;
+    if (x < L.w) {
+      const int2 xt  = b.xtab[L.xtabOff + x];
+      const int  sx  = xt.x;
+      const int  sx1 = min(sx + 1, Ls.w - 1);
+      const int  a0 = (short)(xt.y & 0xffff), a1 = xt.y >> 16;
+      const int  h0 = S0[sx] * a0 + S0[sx1] * a1;
+      const int  h1 = S1[sx] * a0 + S1[sx1] * a1;
+      const int  v  = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+      out |= (uint32_t)(v & 0xff) << (8 * k);
+    }
+  }
+  *reinterpret_cast<uint32_t*>(D + dx) = out;  // pitch is a multiple of 64: the padded tail is writable
+}
+
+// ------------------------------------------------------------------------------------------------
+// cv::FAST(cell, kps, iniThFAST, true) with the minThFAST retry, per cell (src/ORBextractor.cc:777-849).
+//
+// The corner score of OpenCV (cornerScore<16>) is max(A, B) - 1 with
+//   A = max over the 16 arcs of 9 contiguous circle pixels of min(v - p), B likewise for (p - v),
+// and a pixel is a corner at threshold t iff max(A, B) > t, i.e. score >= t.  So one score map serves
+// both thresholds: pass(t) keeps s_t = (score >= t ? score : 0) and applies the strict 3x3 NMS on
+// s_t, with neighbours outside the cell's 3-px-inset interior counting as 0 (they are never scored
+// by cv::FAST on the sub-image).  Output order is row-major, as cv::FAST emits.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int fast_score(const uint8_t (*tile)[kFastTileMax], int x, int y) {
+  const int v = tile[y][x];
+  int       d[16];
+  d[0]  = v - tile[y + 3][x];
+  d[1]  = v - tile[y + 3][x + 1];
+  d[2]  = v - tile[y + 2][x + 2];
+  d[3]  = v - tile[y + 1][x + 3];
+  d[4]  = v - tile[y][x + 3];
+  d[5]  = v - tile[y - 1][x + 3];
+  d[6]  = v - tile[y - 2][x + 2];
+  d[7]  = v - tile[y - 3][x + 1];
+  d[8]  = v - tile[y - 3][x];
+  d[9]  = v - tile[y - 3][x - 1];
+  d[10] = v - tile[y - 2][x - 2];
+  d[11] = v - tile[y - 1][x - 3];
+  d[12] = v - tile[y][x - 3];
+  d[13] = v - tile[y + 1][x - 3];
+  d[14] = v - tile[y + 2][x - 2];
+  d[15] = v - tile[y + 3][x - 1];
+  int mn2[16], mx2[16], mn4[16], mx4[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    mn2[i] = min(d[i], d[(i + 1) & 15]);
+    mx2[i] = max(d[i], d[(i + 1) & 15]);
+  }
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    mn4[i] = min(mn2[i], mn2[(i + 2) & 15]);
+    mx4[i] = max(mx2[i], mx2[(i + 2) & 15]);
+  }
+  int A = -1000, Bm = 1000;
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    const int m9 = min(min(mn4[i], mn4[(i + 4) & 15]), d[(i + 8) & 15]);
+    const int M9 = max(max(mx4[i], mx4[(i + 4) & 15]), d[(i + 8) & 15]);
+    A            = max(A, m9);
+    Bm           = min(Bm, M9);
+  }
+  return max(A, -Bm) - 1;
+}
+
+__global__ __launch_bounds__(256) void k_fast_cells(Bufs b, FrameGeom g, int iniTh, int minTh) {
+  __shared__ uint8_t tile[kFastTileMax][kFastTileMax];
+  __shared__ uint8_t score[kFastTileMax][kFastTileMax];
+  __shared__ int     wavePre[2][24][4];  // per (threshold, iteration, wave) keypoint counts -> exclusive offsets
+  __shared__ int     selTh, selTot;
+  const int          cell = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
+  int                level = 0;
+  while (level + 1 < g.nlevels && cell >= g.lv[level + 1].cellBase) level++;
+  const LevelGeom& L  = g.lv[level];
+  const int        ci = cell - L.cellBase;
+  const int        ci_i = ci / L.nCols, ci_j = ci - ci_i * L.nCols;
+  int*             cntOut = b.cellCount + (long long)f * g.totalCells + cell;
+  const int        iniY = kMinBorder + ci_i * L.hCell, iniX = kMinBorder + ci_j * L.wCell;
+  if (iniY >= L.maxBY - 3 || iniX >= L.maxBX - 6) {  // skip rules (:782-793)
+    if (tid == 0) *cntOut = 0;
+    return;
+  }
+  const int maxY = min(iniY + L.hCell + 6, L.maxBY), maxX = min(iniX + L.wCell + 6, L.maxBX);
+  const int tw = maxX - iniX, th = maxY - iniY;
+  const int iw = tw - 6, ih = th - 6;  // interior scored by cv::FAST
+  if (iw <= 0 || ih <= 0) {
+    if (tid == 0) *cntOut = 0;
+    return;
+  }
+  int            pitch;
+  const uint8_t* img = level_raw(b, g, level, f, &pitch) + (long long)iniY * pitch + iniX;
+  for (int idx = tid; idx < tw * th; idx += 256) {
+    const int y = idx / tw, x = idx - y * tw;
+    tile[y][x]  = img[(long long)y * pitch + x];
+    score[y][x] = 0;
+  }
+  __syncthreads();
+  const int npix  = iw * ih;
+  const int lowTh = max(min(iniTh, minTh), 1);
+  for (int idx = tid; idx < npix; idx += 256) {
+    const int y = 3 + idx / iw, x = 3 + idx % iw;
+    const int s = fast_score(tile, x, y);
+    score[y][x] = (uint8_t)(s >= lowTh ? s : 0);  // scores below both thresholds are never corners
+  }
+  __syncthreads();
+  // strict 3x3 NMS under both thresholds; per-(iteration, wave) counts.  (iteration, wave, lane) order is
+  // the row-major pixel order cv::FAST emits in.
+  const int lane = tid & 63, wave = tid >> 6;
+  const int niter = (npix + 255) >> 8;  // <= 20 (interior <= 71 x 71)
+  for (int it = 0; it < niter; it++) {
+    const int idx = it * 256 + tid;
+    bool      f1 = false, f2 = false;
+    if (idx < npix) {
+      const int y = 3 + idx / iw, x = 3 + idx % iw;
+      const int s = score[y][x];
+      if (s > 0) {
+        int m1 = 0, m2 = 0;  // max neighbour score under each threshold
+#pragma unroll
+        for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+          for (int dx = -1; dx <= 1; dx++)
+            if (dx | dy) {
+              const int t = score[y + dy][x + dx];
+              m2          = max(m2, t);
+              m1          = max(m1, t >= iniTh ? t : 0);
+            }
+        f1 = (s >= iniTh && s > m1);
+        f2 = (s > m2);
+      }
+    }
+    const unsigned long long b1 = __ballot(f1), b2 = __ballot(f2);
+    if (lane == 0) {
+      wavePre[0][it][wave] = __popcll(b1);
+      wavePre[1][it][wave] = __popcll(b2);
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int tot1 = 0;
+    for (int it = 0; it < niter; it++)
+      for (int w = 0; w < 4; w++) tot1 += wavePre[0][it][w];
+    const int sel = tot1 > 0 ? 0 : 1;  // vKeysCell.empty() -> retry with minThFAST (:810-839)
+    int       run = 0;
+    for (int it = 0; it < niter; it++)
+      for (int w = 0; w < 4; w++) {
+        const int c         = wavePre[sel][it][w];
+        wavePre[sel][it][w] = run;
+        run += c;
+      }
+    selTh  = sel;
+    selTot = run;
+    *cntOut = run;
+  }
+  __syncthreads();
+  if (selTot == 0) return;
+  const int sel = selTh;
+  const int thr = sel == 0 ? iniTh : minTh;
+  uint32_t* out = b.slots + (long long)f * g.totalSlots + L.slotBase + b.cellSlot[cell];
+  for (int it = 0; it < niter; it++) {
+    const int idx  = it * 256 + tid;
+    bool      flag = false;
+    int       x = 0, y = 0, s = 0;
+    if (idx < npix) {
+      y = 3 + idx / iw, x = 3 + idx % iw;
+      s = score[y][x];
+      if (s >= thr) {
+        int m = 0;
+#pragma unroll
+        for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+          for (int dx = -1; dx <= 1; dx++)
+            if (dx | dy) {
+              const int t = score[y + dy][x + dx];
+              m           = max(m, t >= thr ? t : 0);
+            }
+        flag = s > m;
+      }
+    }
+    const unsigned long long bal = __ballot(flag);
+    if (flag) {
+      const int pos = wavePre[sel][it][wave] + __popcll(bal & ((1ull << lane) - 1ull));
+      out[pos]      = (uint32_t)(x + ci_j * L.wCell) | ((uint32_t)(y + ci_i * L.hCell) << 12) | ((uint32_t)s << 24);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// DistributeOctTree: one workgroup per (frame, level).  First gathers the per-cell candidate slots into
+// the feed order of the reference (cells row-major, row-major inside a cell), then runs octree_core.h.
+// ------------------------------------------------------------------------------------------------
+constexpr int kOctThreads  = 512;
+constexpr int kOctLdsSort  = 2048;
+
+__device__ __forceinline__ void octree_args(const Bufs& b, const FrameGeom& g, int f, int level, OtArgs* a) {
+  const LevelGeom& L  = g.lv[level];
+  const long long  po = (long long)f * g.totalSlots + L.slotBase;
+  const long long  no = (long long)f * g.totalNodes + L.nodeBase;
+  a->cand    = b.cand + po;
+  a->W       = L.maxBX - kMinBorder;
+  a->H       = L.maxBY - kMinBorder;
+  a->N       = L.N;
+  a->nIni    = L.nIni;
+  a->hX      = L.hX;
+  a->maxNodes = L.nodeCap;
+  a->ordA = b.ordA + po, a->ordB = b.ordB + po, a->nodeOfA = b.nodeOfA + po, a->nodeOfB = b.nodeOfB + po, a->P = b.P + po;
+  a->qv     = b.qv + po;
+  a->nodesA = b.nodesA + no, a->nodesB = b.nodesB + no, a->startCnt = b.startCnt + no, a->endCnt = b.endCnt + no;
+  a->D = b.D + no, a->dIndex = b.dIndex + no, a->nCh = b.nCh + no, a->pushOff = b.pushOff + no, a->multiOff = b.multiOff + no;
+  a->keptRank = b.keptRank + no, a->vA = b.vA + no, a->vB = b.vB + no, a->sortbuf = b.sortbuf + no;
+  a->outKp    = b.lvlKp + (long long)f * g.totalKp + L.kpBase;
+  a->outCount = b.lvlCount + (long long)f * g.nlevels + level;
+}
+
+__global__ __launch_bounds__(kOctThreads) void k_octree(Bufs b, FrameGeom g) {
+  __shared__ int                scratch[80];
+  __shared__ unsigned long long ldsSort[kOctLdsSort];
+  const int                     level = blockIdx.x, f = blockIdx.y;
+  const LevelGeom&              L = g.lv[level];
+  DevCtx                        c;
+  c.tid = threadIdx.x, c.nt = kOctThreads, c.lds = scratch;
+  OtArgs a;
+  octree_args(b, g, f, level, &a);
+  if (L.nodeCap <= kOctLdsSort) a.sortbuf = ldsSort;
+  // feed order: exclusive scan of the cell counts, then copy the slots
+  const int  nc     = L.nCols * L.nRows;
+  const int* counts = b.cellCount + (long long)f * g.totalCells + L.cellBase;
+  int*       offs   = a.P;  // scratch (nc <= slotCount)
+  int        lo, hi;
+  ot_chunk(c, nc, &lo, &hi);
+  Int4 loc = {{0, 0, 0, 0}};
+  for (int i = lo; i < hi; i++) loc.v[0] += counts[i];
+  Int4 tot;
+  Int4 ex  = c.scan4(loc, &tot);
+  int  run = ex.v[0];
+  for (int i = lo; i < hi; i++) {
+    offs[i] = run;
+    run += counts[i];
+  }
+  __syncthreads();
+  const int        n     = tot.v[0];
+  const uint32_t*  slots = b.slots + (long long)f * g.totalSlots + L.slotBase;
+  const int*       cslot = b.cellSlot + L.cellBase;
+  uint32_t*        cand  = b.cand + (long long)f * g.totalSlots + L.slotBase;
+  for (int cidx = c.tid; cidx < nc; cidx += c.nt) {
+    const int cnt = counts[cidx], o = offs[cidx], sb = cslot[cidx];
+    for (int k = 0; k < cnt; k++) cand[o + k] = slots[sb + k];
+  }
+  if (c.tid == 0) b.candCount[(long long)f * g.nlevels + level] = n;
+  __syncthreads();
+  a.n = n;
+  ot_distribute(c, a);
+}
+
+// stand-alone quadtree on caller-supplied candidates (parity hook)
+__global__ __launch_bounds__(kOctThreads) void k_octree_only(OtArgs a) {
+  __shared__ int scratch[80];
+  DevCtx         c;
+  c.tid = threadIdx.x, c.nt = kOctThreads, c.lds = scratch;
+  ot_distribute(c, a);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Output layout of operator() (src/ORBextractor.cc:1090-1134): natural order is level-major / list
+// order; keypoints whose scaled x lies in [lap0, lap1] fill the output from the back, the others from
+// the front.  One workgroup per frame computes every keypoint's output row.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_layout(Bufs b, FrameGeom g, int lap0, int lap1, int* counts, int cap) {
+  __shared__ int scratch[80];
+  const int      f = blockIdx.x;
+  DevCtx         c;
+  c.tid = threadIdx.x, c.nt = 256, c.lds = scratch;
+  const int* lc = b.lvlCount + (long long)f * g.nlevels;
+  int        n  = 0;
+  int        lbase[kMaxLevels + 1];
+  for (int l = 0; l < g.nlevels; l++) {
+    lbase[l] = n;
+    n += lc[l];
+  }
+  lbase[g.nlevels] = n;
+  const uint32_t* kp  = b.lvlKp + (long long)f * g.totalKp;
+  int*            oix = b.outIdx + (long long)f * g.totalKp;
+  int             lo, hi;
+  ot_chunk(c, n, &lo, &hi);
+  auto pred = [&](int i) -> bool {
+    int l = 0;
+    while (l + 1 < g.nlevels && i >= lbase[l + 1]) l++;
+    const uint32_t r  = kp[g.lv[l].kpBase + (i - lbase[l])];
+    float          xs = (float)(ot_cx(r) + kMinBorder);
+    if (l != 0) xs = xs * g.lv[l].scale;
+    return xs >= (float)lap0 && xs <= (float)lap1;
+  };
+  Int4 loc = {{0, 0, 0, 0}};
+  for (int i = lo; i < hi; i++) loc.v[0] += pred(i) ? 1 : 0;
+  Int4 tot;
+  Int4 ex     = c.scan4(loc, &tot);
+  int  stereo = ex.v[0];
+  for (int i = lo; i < hi; i++) {
+    const bool p = pred(i);
+    oix[i]       = p ? (n - 1 - stereo) : (i - stereo);
+    stereo += p ? 1 : 0;
+  }
+  if (c.tid == 0) {
+    counts[2 * f]     = n;
+    counts[2 * f + 1] = n - tot.v[0];  // monoIndex
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// cv::GaussianBlur(7x7, sigma 2, BORDER_REFLECT_101) fixed point: Q8 taps
+// {18,34,48,56,48,34,18}; horizontal pass exact in u16, vertical (sum + 32768) >> 16.
+// Tile = 64 x 16 outputs, staged with a 3-px reflected halo in LDS.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int reflect101(int p, int n) {
+  if (n == 1) return 0;
+  while (p < 0 || p >= n) p = p < 0 ? -p : 2 * n - 2 - p;
+  return p;
+}
+
+__global__ __launch_bounds__(256) void k_blur_levels(Bufs b, FrameGeom g) {
+  __shared__ uint8_t  in[kBlurTileH + 6][kBlurTileW + 8];
+  __shared__ uint16_t hb[kBlurTileH + 6][kBlurTileW];
+  const int           f = blockIdx.y, tid = threadIdx.x;
+  int                 t = blockIdx.x, level = 0;
+  while (level + 1 < g.nlevels && t >= g.lv[level + 1].blurTileBase) level++;
+  const LevelGeom& L = g.lv[level];
+  t -= L.blurTileBase;
+  const int      ty = t / L.blurTilesX, tx = t - ty * L.blurTilesX;
+  const int      x0 = tx * kBlurTileW, y0 = ty * kBlurTileH;
+  int            pitch;
+  const uint8_t* src = level_raw(b, g, level, f, &pitch);
+  for (int idx = tid; idx < (kBlurTileH + 6) * (kBlurTileW + 6); idx += 256) {
+    const int yy = idx / (kBlurTileW + 6), xx = idx - yy * (kBlurTileW + 6);
+    const int sy = reflect101(min(y0 + yy - 3, L.h + 2), L.h), sx = reflect101(min(x0 + xx - 3, L.w + 2), L.w);
+    in[yy][xx]   = src[(long long)sy * pitch + sx];
+  }
+  __syncthreads();
+  for (int idx = tid; idx < (kBlurTileH + 6) * kBlurTileW; idx += 256) {
+    const int yy = idx / kBlurTileW, xx = idx - yy * kBlurTileW;
+    const int s  = 18 * (in[yy][xx] + in[yy][xx + 6]) + 34 * (in[yy][xx + 1] + in[yy][xx + 5]) + 48 * (in[yy][xx + 2] + in[yy][xx + 4]) +
+                  56 * in[yy][xx + 3];
+    hb[yy][xx] = (uint16_t)s;
+  }
+  __syncthreads();
+  uint8_t* dst = b.blur + (long long)f * g.blurBytes + L.blurOff;
+  // thread = 4 adjacent outputs of one row
+  const int oy = tid >> 4, ox = (tid & 15) * 4;
+  if (y0 + oy < L.h && x0 + ox < L.w) {
+    uint32_t out = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int      xx = ox + k;
+      const uint32_t s  = 18u * (hb[oy][xx] + hb[oy + 6][xx]) + 34u * (hb[oy + 1][xx] + hb[oy + 5][xx]) +
+                         48u * (hb[oy + 2][xx] + hb[oy + 4][xx]) + 56u * hb[oy + 3][xx];
+      out |= ((s + 32768u) >> 16) << (8 * k);
+    }
+    *reinterpret_cast<uint32_t*>(dst + (long long)(y0 + oy) * L.blurPitch + x0 + ox) = out;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// IC_Angle (:66-91) + computeOrbDescriptor (:94-139) + output record (:1115-1134): one wave per keypoint.
+// ------------------------------------------------------------------------------------------------
+struct PatternTab {
+  signed char v[1024];
+};
+
+__device__ __forceinline__ float fast_atan2_deg(float y, float x) {  // cv::fastAtan2 scalar path
+  const float p1 = 0.9997878412794807f * (float)(180 / 3.14159265358979323846);
+  const float p3 = -0.3258083974640975f * (float)(180 / 3.14159265358979323846);
+  const float p5 = 0.1555786518463281f * (float)(180 / 3.14159265358979323846);
+  const float p7 = -0.04432655554792128f * (float)(180 / 3.14159265358979323846);
+  const float eps = (float)2.2204460492503131e-16;
+  const float ax = fabsf(x), ay = fabsf(y);
+  float       a, c, c2;
+  if (ax >= ay) {
+    c  = ay / (ax + eps);
+    c2 = c * c;
+    a  = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+  } else {
+    c  = ax / (ay + eps);
+    c2 = c * c;
+    a  = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+  }
+  if (x < 0) a = 180.f - a;
+  if (y < 0) a = 360.f - a;
+  return a;
+}
+
+__constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};  // src/ORBextractor.cc:448-464
+
+__global__ __launch_bounds__(256) void k_orient_describe(Bufs b, FrameGeom g, const PatternTab* __restrict__ pat, const int* counts,
+                                                          KpRec* kps, uint8_t* desc, int cap) {
+  const int f = blockIdx.y, lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int n = counts[2 * f];
+  if (i >= n) return;
+  const int* lc = b.lvlCount + (long long)f * g.nlevels;
+  int        level = 0, base = 0;
+  while (level + 1 < g.nlevels && i >= base + lc[level]) {
+    base += lc[level];
+    level++;
+  }
+  const LevelGeom& L  = g.lv[level];
+  const uint32_t   r  = b.lvlKp[(long long)f * g.totalKp + L.kpBase + (i - base)];
+  const int        px = ot_cx(r) + kMinBorder, py = ot_cy(r) + kMinBorder;
+  // ---- orientation on the raw level
+  int            pitch;
+  const uint8_t* img    = level_raw(b, g, level, f, &pitch);
+  const uint8_t* center = img + (long long)py * pitch + px;
+  int            m10 = 0, m01 = 0;
+  {
+    const int half = lane >> 5, u = (lane & 31) - 15;  // lanes 0..30 -> +v rows, 32..62 -> -v rows
+    if ((lane & 31) < 31) {
+      if (half == 0) m10 += u * center[u];  // v = 0 row once
+#pragma unroll
+      for (int v = 1; v <= kHalfPatch; v++) {
+        const int d = c_umax[v];
+        if (u >= -d && u <= d) {
+          const int val = half == 0 ? center[u + v * pitch] : center[u - v * pitch];
+          m10 += u * val;
+          m01 += half == 0 ? v * val : -v * val;
+        }
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      m10 += __shfl_xor(m10, off, 64);
+      m01 += __shfl_xor(m01, off, 64);
+    }
+  }
+  const float angle = fast_atan2_deg((float)m01, (float)m10);
+  // ---- steered BRIEF on the blurred level
+  const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
+  float       sn, cs;
+  orbport::sincosf_port<false>(angle * factorPI, &sn, &cs);
+  const float    a = cs, bb = sn;
+  const uint8_t* bl = b.blur + (long long)f * g.blurBytes + L.blurOff + (long long)py * L.blurPitch + px;
+  const int      bp = L.blurPitch;
+  unsigned long long words[4];
+#pragma unroll
+  for (int w = 0; w < 4; w++) {
+    const int   pair = w * 64 + lane;
+    const char4 p4   = *reinterpret_cast<const char4*>(&pat->v[pair * 4]);
+    const float x0 = (float)p4.x, y0 = (float)p4.y, x1 = (float)p4.z, y1 = (float)p4.w;
+    const int   r0 = __float2int_rn(x0 * bb + y0 * a), c0 = __float2int_rn(x0 * a - y0 * bb);
+    const int   r1 = __float2int_rn(x1 * bb + y1 * a), c1 = __float2int_rn(x1 * a - y1 * bb);
+    const int   t0 = bl[r0 * bp + c0], t1 = bl[r1 * bp + c1];
+    words[w]       = __ballot(t0 < t1);
+  }
+  // ---- output row
+  const int row = b.outIdx[(long long)f * g.totalKp + i];
+  if (row < cap) {
+    if (lane < 4) {
+      unsigned long long wv = lane == 0 ? words[0] : lane == 1 ? words[1] : lane == 2 ? words[2] : words[3];
+      *reinterpret_cast<unsigned long long*>(desc + ((long long)f * cap + row) * 32 + lane * 8) = wv;
+    }
+    if (lane == 0) {
+      KpRec k;
+      k.x = (float)px;
+      k.y = (float)py;
+      if (level != 0) {
+        k.x = k.x * L.scale;
+        k.y = k.y * L.scale;
+      }
+      k.size     = (float)L.patchSize;
+      k.angle    = angle;
+      k.response = (float)ot_cr(r);
+      k.octave   = level;
+      k.class_id = -1;
+      kps[(long long)f * cap + row] = k;
+    }
+  }
+}
+
+}  // namespace orbx
+#endif

@@ -1,0 +1,843 @@
+// orbx_matcher.hip -- Hamming matcher kernels + C ABI (include/orbx.h, orbm_*) on gfx950.
+//
+// Every ORBmatcher search bottoms out in: for a query descriptor scan a candidate list, keep best and
+// second-best Hamming distance, threshold + ratio test, then a rotation-histogram vote
+// (reference src/ORBmatcher.cc:286-360).  Two things make that loop order-dependent in the reference:
+//   * SearchByBoW skips train features already claimed by an earlier query (:290-292 / :837),
+//   * SearchForInitialization skips candidates whose recorded distance is not worse (:713) and
+//     re-assigns train features (:728-735).
+// The GPU form keeps the semantics exactly while doing the distance work in parallel:
+//   1. k_*_topk: one wave per query computes all distances of its candidate list (64 lanes x
+//      popcount of 256-bit XOR) and keeps the K smallest (distance, scan position) keys -- the order the
+//      reference's strict `<` updates induce.  Claims only ever *remove* candidates, so the first two
+//      surviving entries of that sorted list are the reference's best / second-best ...
+//   2. k_*_resolve: one wave walks the queries in reference order with the claim state in LDS, consults
+//      the K-lists, and falls back to a wave-parallel rescan only when a truncated list runs dry.
+// No MFMA: this is xor + popcount + integer compare (VALU), inputs are tens of KB.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/orbx.h"
+
+namespace {
+
+constexpr int      kTopK       = 4;
+constexpr uint32_t kEmpty      = 0xffffffffu;
+constexpr int      kPosBits    = 22;
+constexpr uint32_t kPosMask    = (1u << kPosBits) - 1u;
+constexpr int      kHistoLen   = 30;     // ORBmatcher::HISTO_LENGTH (src/ORBmatcher.cc:32)
+constexpr int      kMaxTrain   = 65536;  // claim bitmap in LDS
+constexpr int      kMaxTrainW  = 16384;  // vMatchedDistance (u16) in LDS
+constexpr int      kGridCols = 64, kGridRows = 48;  // FRAME_GRID_COLS / ROWS (include/Frame.h:36-37)
+
+#define HIP_TRYM(expr)                                                                                  \
+  do {                                                                                                  \
+    hipError_t e_ = (expr);                                                                             \
+    if (e_ != hipSuccess) {                                                                             \
+      set_err(std::string(#expr) + ": " + hipGetErrorString(e_));                                       \
+      return -3;                                                                                        \
+    }                                                                                                   \
+  } while (0)
+
+thread_local std::string g_merr;
+void                     set_err(const std::string& s) { g_merr = s; }
+
+__device__ __forceinline__ int hamming256(const uint4& a0, const uint4& a1, const uint8_t* __restrict__ p) {
+  const uint4 b0 = *reinterpret_cast<const uint4*>(p);
+  const uint4 b1 = *reinterpret_cast<const uint4*>(p + 16);
+  return __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) + __popc(a1.x ^ b1.x) +
+         __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
+}
+
+__device__ __forceinline__ void topk_insert(uint32_t (&k)[kTopK], uint32_t key) {
+#pragma unroll
+  for (int j = 0; j < kTopK; j++) {
+    if (key < k[j]) {
+      const uint32_t t = k[j];
+      k[j]             = key;
+      key              = t;
+    }
+  }
+}
+
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, off, 64));
+  return v;
+}
+__device__ __forceinline__ int wave_sum_i32(int v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// Scan positions [lo, hi) with 64 lanes; cand(pos) returns the train row or -1 (filtered);
+// dist_ok(row, dist) is a second, distance-dependent filter.  All lanes return the K smallest keys.
+template <class CandFn, class DistFn>
+__device__ __forceinline__ void wave_topk(const uint8_t* __restrict__ qd, const uint8_t* __restrict__ tdesc, int lo, int hi, CandFn cand,
+                                          DistFn dist_ok, uint32_t (&out)[kTopK], int* nvalid) {
+  const int   lane = threadIdx.x & 63;
+  const uint4 a0 = *reinterpret_cast<const uint4*>(qd), a1 = *reinterpret_cast<const uint4*>(qd + 16);
+  uint32_t    k[kTopK];
+#pragma unroll
+  for (int j = 0; j < kTopK; j++) k[j] = kEmpty;
+  int cnt = 0;
+  for (int pos = lo + lane; pos < hi; pos += 64) {
+    const int row = cand(pos);
+    if (row < 0) continue;
+    const int d = hamming256(a0, a1, tdesc + (size_t)row * 32);
+    if (!dist_ok(row, d)) continue;
+    cnt++;
+    topk_insert(k, ((uint32_t)d << kPosBits) | (uint32_t)pos);
+  }
+#pragma unroll
+  for (int j = 0; j < kTopK; j++) {
+    const uint32_t m = wave_min_u32(k[0]);
+    out[j]           = m;
+    if (m != kEmpty && k[0] == m) {  // positions are unique: exactly one lane pops
+#pragma unroll
+      for (int t = 0; t + 1 < kTopK; t++) k[t] = k[t + 1];
+      k[kTopK - 1] = kEmpty;
+    }
+  }
+  *nvalid = wave_sum_i32(cnt);
+}
+
+__device__ __forceinline__ int rot_bin(float a1, float a2) {  // src/ORBmatcher.cc:348-357
+  const float factor = 1.0f / kHistoLen;
+  float       rot    = a1 - a2;
+  if (rot < 0.0f) rot += 360.0f;
+  int bin = (int)roundf(rot * factor);
+  if (bin == kHistoLen) bin = 0;
+  return bin;
+}
+
+__device__ __forceinline__ void three_maxima(const int* histo, int L, int& ind1, int& ind2, int& ind3) {  // :2038-2071
+  int max1 = 0, max2 = 0, max3 = 0;
+  ind1 = ind2 = ind3 = -1;
+  for (int i = 0; i < L; i++) {
+    const int s = histo[i];
+    if (s > max1) {
+      max3 = max2, max2 = max1, max1 = s;
+      ind3 = ind2, ind2 = ind1, ind1 = i;
+    } else if (s > max2) {
+      max3 = max2, max2 = s;
+      ind3 = ind2, ind2 = i;
+    } else if (s > max3) {
+      max3 = s, ind3 = i;
+    }
+  }
+  if (max2 < 0.1f * (float)max1) {
+    ind2 = -1, ind3 = -1;
+  } else if (max3 < 0.1f * (float)max1) {
+    ind3 = -1;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// SearchByBoW over flattened groups
+// ------------------------------------------------------------------------------------------------
+struct GroupArgs {
+  const uint8_t *q, *t;
+  const int *    d_nq, *d_nt;  // optional device-side counts (brute-force stream form); else nq / nt
+  int            nq, nt, ngroups, nqe;  // nqe = entries of the query lists (== nq for brute force)
+  const int *    q_off, *q_idx, *t_off, *t_idx;  // NULL q_idx/t_idx = identity (ngroups == 1)
+  const uint8_t *q_valid, *t_valid;
+  const float *  q_angle, *t_angle;
+  int            q_astride, t_astride;  // in floats
+  int            th, strict_lt, check_ori;
+  float          ratio;
+  uint32_t*      topk;       // [nqe][kTopK]
+  int*           nvalid;     // [nqe] candidates seen by the top-k pass
+  int*           binOf;      // [nq]
+  int *          match_t_of_q, *match_q_of_t, *nmatches;
+  // batch form: blockIdx.y = pair p; pairs[2p] / pairs[2p+1] = query / train frame of a
+  // [frames][cap] x 32 B descriptor block (orbx_extract_batch_device layout); NULL = single pair
+  const int* pairs;
+  const int* counts;  // [frames][2]: n, monoIndex
+  int        cap;
+};
+
+// Per-pair view of the batch form.
+__device__ __forceinline__ GroupArgs pair_view(const GroupArgs& a, int p) {
+  if (!a.pairs) return a;
+  GroupArgs v = a;
+  const int fq = a.pairs[2 * p], ft = a.pairs[2 * p + 1];
+  v.q       = a.q + (size_t)fq * a.cap * 32;
+  v.t       = a.t + (size_t)ft * a.cap * 32;
+  v.d_nq    = a.counts + 2 * fq;
+  v.d_nt    = a.counts + 2 * ft;
+  v.q_angle = a.q_angle ? a.q_angle + (size_t)fq * a.cap * a.q_astride : nullptr;
+  v.t_angle = a.t_angle ? a.t_angle + (size_t)ft * a.cap * a.t_astride : nullptr;
+  v.topk    = a.topk + (size_t)p * a.cap * kTopK;
+  v.nvalid  = a.nvalid + (size_t)p * a.cap;
+  v.binOf   = a.binOf + (size_t)p * a.cap;
+  v.match_t_of_q = a.match_t_of_q + (size_t)p * a.cap;
+  v.match_q_of_t = a.match_q_of_t + (size_t)p * a.cap;
+  v.nmatches     = a.nmatches + p;
+  return v;
+}
+
+__device__ __forceinline__ int group_of(const GroupArgs& a, int e) {
+  int lo = 0, hi = a.ngroups - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (a.q_off[mid] <= e)
+      lo = mid;
+    else
+      hi = mid - 1;
+  }
+  return lo;
+}
+
+__global__ __launch_bounds__(256) void k_group_topk(GroupArgs a0) {
+  const GroupArgs a = pair_view(a0, blockIdx.y);
+  const int       e = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int nq  = a.d_nq ? *a.d_nq : a.nq;
+  const int nt  = a.d_nt ? *a.d_nt : a.nt;
+  const int nqe = a.q_idx ? a.nqe : nq;
+  if (e >= nqe) return;
+  int g = 0, lo = 0, hi = nt;
+  if (a.q_idx) {
+    g  = group_of(a, e);
+    lo = a.t_off[g], hi = a.t_off[g + 1];
+  }
+  const int rq = a.q_idx ? a.q_idx[e] : e;
+  uint32_t  out[kTopK];
+  int       nv = 0;
+  if (a.q_valid && !a.q_valid[rq]) {
+#pragma unroll
+    for (int j = 0; j < kTopK; j++) out[j] = kEmpty;
+  } else {
+    const int*     t_idx   = a.t_idx;
+    const uint8_t* t_valid = a.t_valid;
+    wave_topk(
+        a.q + (size_t)rq * 32, a.t, lo, hi,
+        [t_idx, t_valid](int pos) {
+          const int row = t_idx ? t_idx[pos] : pos;
+          return (t_valid && !t_valid[row]) ? -1 : row;
+        },
+        [](int, int) { return true; }, out, &nv);
+  }
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int j = 0; j < kTopK; j++) a.topk[(size_t)e * kTopK + j] = out[j];
+    a.nvalid[e] = nv;
+  }
+}
+
+__global__ __launch_bounds__(64) void k_group_resolve(GroupArgs a0) {
+  const GroupArgs     a = pair_view(a0, blockIdx.x);
+  __shared__ uint32_t claimed[kMaxTrain / 32];
+  __shared__ int      hist[kHistoLen];
+  const int           lane = threadIdx.x;
+  const int           nq   = a.d_nq ? *a.d_nq : a.nq;
+  const int           nt   = a.d_nt ? *a.d_nt : a.nt;
+  const int           nqe  = a.q_idx ? a.nqe : nq;
+  for (int i = lane; i < (nt + 31) / 32; i += 64) claimed[i] = 0;
+  for (int i = lane; i < kHistoLen; i += 64) hist[i] = 0;
+  for (int i = lane; i < nq; i += 64) a.match_t_of_q[i] = -1;
+  for (int i = lane; i < nt; i += 64) a.match_q_of_t[i] = -1;
+  __syncthreads();
+  int nmatches = 0;
+  for (int e0 = 0; e0 < nqe; e0 += 64) {
+    // queries whose unconstrained best already fails the threshold can never match: claims only remove candidates
+    const int e   = e0 + lane;
+    bool      pos = false;
+    if (e < nqe) {
+      const uint32_t k0 = a.topk[(size_t)e * kTopK];
+      if (k0 != kEmpty) {
+        const int d = (int)(k0 >> kPosBits);
+        pos         = a.strict_lt ? d < a.th : d <= a.th;
+      }
+    }
+    unsigned long long mask = __ballot(pos);
+    while (mask) {
+      const int b  = __ffsll((long long)mask) - 1;
+      mask &= mask - 1;
+      const int ee = e0 + b;
+      const int rq = a.q_idx ? a.q_idx[ee] : ee;
+      int       best = 256, second = 256, bestT = -1, found = 0;
+      for (int j = 0; j < kTopK && found < 2; j++) {
+        const uint32_t key = a.topk[(size_t)ee * kTopK + j];
+        if (key == kEmpty) break;
+        const int p   = (int)(key & kPosMask);
+        const int row = a.t_idx ? a.t_idx[p] : p;
+        if (claimed[row >> 5] & (1u << (row & 31))) continue;
+        const int d = (int)(key >> kPosBits);
+        if (found == 0) {
+          best = d, bestT = row;
+        } else {
+          second = d;
+        }
+        found++;
+      }
+      if (found < 2 && a.nvalid[ee] > kTopK) {
+        // the K-list was truncated and ran dry: exact rescan of the group with the claim filter
+        int lo = 0, hi = nt;
+        if (a.q_idx) {
+          const int g = group_of(a, ee);
+          lo = a.t_off[g], hi = a.t_off[g + 1];
+        }
+        const int*      t_idx   = a.t_idx;
+        const uint8_t*  t_valid = a.t_valid;
+        const uint32_t* cl      = claimed;
+        uint32_t        out[kTopK];
+        int             nv;
+        wave_topk(
+            a.q + (size_t)rq * 32, a.t, lo, hi,
+            [t_idx, t_valid, cl](int p) {
+              const int row = t_idx ? t_idx[p] : p;
+              if (t_valid && !t_valid[row]) return -1;
+              return (cl[row >> 5] & (1u << (row & 31))) ? -1 : row;
+            },
+            [](int, int) { return true; }, out, &nv);
+        best = 256, second = 256, bestT = -1;
+        if (out[0] != kEmpty) {
+          const int p = (int)(out[0] & kPosMask);
+          best        = (int)(out[0] >> kPosBits);
+          bestT       = a.t_idx ? a.t_idx[p] : p;
+        }
+        if (out[1] != kEmpty) second = (int)(out[1] >> kPosBits);
+      }
+      const bool pass = a.strict_lt ? best < a.th : best <= a.th;
+      if (pass && (float)best < a.ratio * (float)second) {
+        if (lane == 0) {
+          claimed[bestT >> 5] |= 1u << (bestT & 31);
+          a.match_t_of_q[rq]    = bestT;
+          a.match_q_of_t[bestT] = rq;
+          if (a.check_ori) {
+            const int bin = rot_bin(a.q_angle[(size_t)rq * a.q_astride], a.t_angle[(size_t)bestT * a.t_astride]);
+            hist[bin]++;
+            a.binOf[rq] = bin;
+          }
+        }
+        nmatches++;
+        __syncthreads();  // single-wave workgroup: orders lane 0's LDS/global writes before the next reads
+      }
+    }
+  }
+  __syncthreads();
+  if (a.check_ori) {
+    int i1, i2, i3;
+    three_maxima(hist, kHistoLen, i1, i2, i3);
+    int removed = 0;
+    for (int q0 = 0; q0 < nq; q0 += 64) {
+      const int q    = q0 + lane;
+      bool      drop = false;
+      if (q < nq) {
+        const int m = a.match_t_of_q[q];
+        if (m >= 0) {
+          const int bin = a.binOf[q];
+          if (bin != i1 && bin != i2 && bin != i3) {
+            drop                = true;
+            a.match_q_of_t[m]   = -1;
+            a.match_t_of_q[q]   = -1;
+          }
+        }
+      }
+      removed += __popcll(__ballot(drop));
+    }
+    nmatches -= removed;
+  }
+  if (lane == 0) *a.nmatches = nmatches;
+}
+
+// ------------------------------------------------------------------------------------------------
+// SearchForInitialization (src/ORBmatcher.cc:666-782)
+// ------------------------------------------------------------------------------------------------
+struct WindowArgs {
+  const uint8_t *d1, *d2;
+  const orbx_keypoint_t *kp1, *kp2;
+  int                    n1, n2, ng;  // ng = level-0, in-grid F2 keypoints in grid scan order
+  const int*             g_idx;       // [ng] F2 keypoint index
+  const uint8_t *        g_cx, *g_cy; // [ng] grid cell
+  float*                 prev;        // [n1][2]
+  float                  minX, minY, gwInv, ghInv, r;
+  int                    th, check_ori;
+  float                  ratio;
+  uint32_t*              topk;
+  int*                   nvalid;
+  int *                  m12, *m21, *binOf, *nmatches;
+};
+
+struct WinRange {
+  int  x0, x1, y0, y1;
+  bool empty;
+};
+
+// Frame::GetFeaturesInArea cell range (src/Frame.cc:802-830)
+__device__ __forceinline__ WinRange window_cells(const WindowArgs& a, float x, float y) {
+  WinRange w;
+  w.x0    = max(0, (int)floorf((x - a.minX - a.r) * a.gwInv));
+  w.x1    = min(kGridCols - 1, (int)ceilf((x - a.minX + a.r) * a.gwInv));
+  w.y0    = max(0, (int)floorf((y - a.minY - a.r) * a.ghInv));
+  w.y1    = min(kGridRows - 1, (int)ceilf((y - a.minY + a.r) * a.ghInv));
+  w.empty = (w.x0 >= kGridCols) || (w.x1 < 0) || (w.y0 >= kGridRows) || (w.y1 < 0);
+  return w;
+}
+
+__global__ __launch_bounds__(256) void k_window_topk(WindowArgs a) {
+  const int i1 = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i1 >= a.n1) return;
+  uint32_t out[kTopK];
+  int      nv = 0;
+#pragma unroll
+  for (int j = 0; j < kTopK; j++) out[j] = kEmpty;
+  if (a.kp1[i1].octave <= 0) {  // level1 > 0 -> continue (:688-690)
+    const float    x = a.prev[2 * i1], y = a.prev[2 * i1 + 1];
+    const WinRange w = window_cells(a, x, y);
+    if (!w.empty) {
+      const WindowArgs& ar = a;
+      wave_topk(
+          a.d1 + (size_t)i1 * 32, a.d2, 0, a.ng,
+          [&ar, w, x, y](int pos) {
+            const int cx = ar.g_cx[pos], cy = ar.g_cy[pos];
+            if (cx < w.x0 || cx > w.x1 || cy < w.y0 || cy > w.y1) return -1;
+            const int   i2 = ar.g_idx[pos];
+            const float dx = ar.kp2[i2].x - x, dy = ar.kp2[i2].y - y;
+            return (fabsf(dx) < ar.r && fabsf(dy) < ar.r) ? i2 : -1;
+          },
+          [](int, int) { return true; }, out, &nv);
+    }
+  }
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int j = 0; j < kTopK; j++) a.topk[(size_t)i1 * kTopK + j] = out[j];
+    a.nvalid[i1] = nv;
+  }
+}
+
+__global__ __launch_bounds__(64) void k_window_resolve(WindowArgs a) {
+  __shared__ unsigned short matchedDist[kMaxTrainW];  // vMatchedDistance; 0xffff = INT_MAX
+  __shared__ int            hist[kHistoLen];
+  const int                 lane = threadIdx.x;
+  for (int i = lane; i < a.n2; i += 64) {
+    matchedDist[i] = 0xffff;
+    a.m21[i]       = -1;
+  }
+  for (int i = lane; i < a.n1; i += 64) a.m12[i] = -1;
+  for (int i = lane; i < kHistoLen; i += 64) hist[i] = 0;
+  __syncthreads();
+  int nmatches = 0;
+  for (int e0 = 0; e0 < a.n1; e0 += 64) {
+    const int e   = e0 + lane;
+    bool      pos = false;
+    if (e < a.n1) {
+      const uint32_t k0 = a.topk[(size_t)e * kTopK];
+      pos               = k0 != kEmpty && (int)(k0 >> kPosBits) <= a.th;
+    }
+    unsigned long long mask = __ballot(pos);
+    while (mask) {
+      const int b = __ffsll((long long)mask) - 1;
+      mask &= mask - 1;
+      const int i1   = e0 + b;
+      int       best = 0x7fffffff, second = 0x7fffffff, best2 = -1, found = 0;
+      for (int j = 0; j < kTopK && found < 2; j++) {
+        const uint32_t key = a.topk[(size_t)i1 * kTopK + j];
+        if (key == kEmpty) break;
+        const int p = (int)(key & kPosMask), d = (int)(key >> kPosBits);
+        const int i2 = a.g_idx[p];
+        if ((int)matchedDist[i2] <= d) continue;  // vMatchedDistance[i2] <= dist (:713)
+        if (found == 0) {
+          best = d, best2 = i2;
+        } else {
+          second = d;
+        }
+        found++;
+      }
+      if (found < 2 && a.nvalid[i1] > kTopK) {
+        const float               x = a.prev[2 * i1], y = a.prev[2 * i1 + 1];
+        const WinRange            w  = window_cells(a, x, y);
+        const WindowArgs&         ar = a;
+        const unsigned short*     md = matchedDist;
+        uint32_t                  out[kTopK];
+        int                       nv;
+        wave_topk(
+            a.d1 + (size_t)i1 * 32, a.d2, 0, a.ng,
+            [&ar, w, x, y](int pos2) {
+              const int cx = ar.g_cx[pos2], cy = ar.g_cy[pos2];
+              if (cx < w.x0 || cx > w.x1 || cy < w.y0 || cy > w.y1) return -1;
+              const int   i2 = ar.g_idx[pos2];
+              const float dx = ar.kp2[i2].x - x, dy = ar.kp2[i2].y - y;
+              return (fabsf(dx) < ar.r && fabsf(dy) < ar.r) ? i2 : -1;
+            },
+            [md](int row, int d) { return !((int)md[row] <= d); }, out, &nv);
+        best = 0x7fffffff, second = 0x7fffffff, best2 = -1;
+        if (out[0] != kEmpty) {
+          best  = (int)(out[0] >> kPosBits);
+          best2 = a.g_idx[out[0] & kPosMask];
+        }
+        if (out[1] != kEmpty) second = (int)(out[1] >> kPosBits);
+      }
+      // bestDist <= TH_LOW && bestDist < (float)bestDist2 * mfNNratio (:723-724)
+      if (best <= a.th && (float)best < (float)second * a.ratio) {
+        if (lane == 0) {
+          const int prevQ = a.m21[best2];
+          if (prevQ >= 0) a.m12[prevQ] = -1;
+          a.m12[i1]          = best2;
+          a.m21[best2]       = i1;
+          matchedDist[best2] = (unsigned short)best;
+          if (a.check_ori) {
+            const int bin = rot_bin(a.kp1[i1].angle, a.kp2[best2].angle);
+            hist[bin]++;
+            a.binOf[i1] = bin;
+          }
+        }
+        __syncthreads();
+      }
+    }
+  }
+  __syncthreads();
+  if (a.check_ori) {
+    int i1m, i2m, i3m;
+    three_maxima(hist, kHistoLen, i1m, i2m, i3m);
+    for (int q = lane; q < a.n1; q += 64) {
+      if (a.m12[q] >= 0) {
+        const int bin = a.binOf[q];
+        if (bin != i1m && bin != i2m && bin != i3m) a.m12[q] = -1;
+      }
+    }
+  }
+  __syncthreads();
+  // nmatches == number of surviving pairs (every increment / decrement of the reference tracks one); prev update (:775-779)
+  for (int q0 = 0; q0 < a.n1; q0 += 64) {
+    const int q  = q0 + lane;
+    bool      on = false;
+    if (q < a.n1 && a.m12[q] >= 0) {
+      on                = true;
+      a.prev[2 * q]     = a.kp2[a.m12[q]].x;
+      a.prev[2 * q + 1] = a.kp2[a.m12[q]].y;
+    }
+    nmatches += __popcll(__ballot(on));
+  }
+  if (lane == 0) *a.nmatches = nmatches;
+}
+
+template <class T>
+struct DBuf {
+  T*     p = nullptr;
+  size_t n = 0;
+  int    ensure(size_t count) {
+    if (count <= n && p) return 0;
+    if (p) hipFree(p);
+    p = nullptr, n = 0;
+    hipError_t e = hipMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T));
+    if (e != hipSuccess) {
+      set_err(std::string("hipMalloc: ") + hipGetErrorString(e));
+      return -3;
+    }
+    n = count;
+    return 0;
+  }
+  void release() {
+    if (p) hipFree(p);
+    p = nullptr, n = 0;
+  }
+};
+
+}  // namespace
+
+struct orbm_matcher {
+  int         device = 0;
+  hipStream_t stream = nullptr;
+  DBuf<uint8_t>         dq, dt, dqv, dtv, gcx, gcy;
+  DBuf<int>             qoff, qidx, toff, tidx, nvalid, binOf, mq, mt, nm, gidx;
+  DBuf<float>           qa, ta, prev;
+  DBuf<uint32_t>        topk;
+  DBuf<orbx_keypoint_t> kp1, kp2;
+};
+
+extern "C" {
+
+int orbm_create(orbm_t** out, int device_id) {
+  if (!out) return -2;
+  *out = nullptr;
+  HIP_TRYM(hipSetDevice(device_id));
+  orbm_matcher* h = new orbm_matcher();
+  h->device       = device_id;
+  hipError_t e    = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    set_err(std::string("hipStreamCreate: ") + hipGetErrorString(e));
+    delete h;
+    return -3;
+  }
+  *out = h;
+  return 0;
+}
+
+void orbm_destroy(orbm_t* h) {
+  if (!h) return;
+  hipSetDevice(h->device);
+  if (h->stream) {
+    hipStreamSynchronize(h->stream);
+    hipStreamDestroy(h->stream);
+  }
+  h->dq.release(), h->dt.release(), h->dqv.release(), h->dtv.release(), h->gcx.release(), h->gcy.release(), h->qoff.release();
+  h->qidx.release(), h->toff.release(), h->tidx.release(), h->nvalid.release(), h->binOf.release(), h->mq.release(), h->mt.release();
+  h->nm.release(), h->gidx.release(), h->qa.release(), h->ta.release(), h->prev.release(), h->topk.release(), h->kp1.release();
+  h->kp2.release();
+  delete h;
+}
+
+int orbm_hamming(const uint8_t* a, const uint8_t* b) {
+  int dist = 0;
+  for (int i = 0; i < 4; i++) {
+    unsigned long long x, y;
+    memcpy(&x, a + 8 * i, 8);
+    memcpy(&y, b + 8 * i, 8);
+    dist += __builtin_popcountll(x ^ y);
+  }
+  return dist;
+}
+
+void orbm_three_maxima(const int* counts, int len, int* ind1, int* ind2, int* ind3) {
+  int max1 = 0, max2 = 0, max3 = 0, i1 = -1, i2 = -1, i3 = -1;
+  for (int i = 0; i < len; i++) {
+    const int s = counts[i];
+    if (s > max1) {
+      max3 = max2, max2 = max1, max1 = s;
+      i3 = i2, i2 = i1, i1 = i;
+    } else if (s > max2) {
+      max3 = max2, max2 = s;
+      i3 = i2, i2 = i;
+    } else if (s > max3) {
+      max3 = s, i3 = i;
+    }
+  }
+  if (max2 < 0.1f * (float)max1) {
+    i2 = -1, i3 = -1;
+  } else if (max3 < 0.1f * (float)max1) {
+    i3 = -1;
+  }
+  *ind1 = i1, *ind2 = i2, *ind3 = i3;
+}
+
+static int launch_groups(orbm_matcher* h, GroupArgs& a, int nq_cap, hipStream_t s, int npairs = 1) {
+  const int nqe = a.q_idx ? a.nqe : nq_cap;
+  if (nqe > 0) hipLaunchKernelGGL(k_group_topk, dim3((nqe + 3) / 4, npairs), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_group_resolve, dim3(npairs), dim3(64), 0, s, a);
+  HIP_TRYM(hipGetLastError());
+  return 0;
+}
+
+int orbm_match_groups(orbm_t* h, const uint8_t* q, int nq, const uint8_t* t, int nt, int ngroups, const int* q_off, const int* q_idx,
+                      const int* t_off, const int* t_idx, const uint8_t* q_valid, const uint8_t* t_valid, const float* q_angle,
+                      const float* t_angle, int th, int strict_lt, float ratio, int check_ori, int* match_t_of_q, int* match_q_of_t) {
+  if (!h || nq < 0 || nt < 0 || (nq > 0 && !q) || (nt > 0 && !t) || ngroups < 1) {
+    set_err("orbm_match_groups: bad arguments");
+    return -2;
+  }
+  const bool grouped = q_idx || t_idx || q_off || t_off;
+  if (grouped && !(q_idx && t_idx && q_off && t_off)) {
+    set_err("orbm_match_groups: q_off, q_idx, t_off, t_idx must be given together");
+    return -2;
+  }
+  if (!grouped && ngroups != 1) {
+    set_err("orbm_match_groups: ngroups > 1 needs the group arrays");
+    return -2;
+  }
+  if (check_ori && (!q_angle || !t_angle)) {
+    set_err("orbm_match_groups: check_ori needs angles");
+    return -2;
+  }
+  if (nt > kMaxTrain || nt >= (1 << kPosBits)) {
+    set_err("orbm_match_groups: more than 65536 train features");
+    return -2;
+  }
+  HIP_TRYM(hipSetDevice(h->device));
+  const int nqe = grouped ? q_off[ngroups] : nq;
+  const int nte = grouped ? t_off[ngroups] : nt;
+  if (grouped) {
+    for (int g = 0; g < ngroups; g++)
+      if (q_off[g] > q_off[g + 1] || t_off[g] > t_off[g + 1] || q_off[g] < 0 || t_off[g] < 0) {
+        set_err("orbm_match_groups: offsets must be non-decreasing");
+        return -2;
+      }
+    for (int i = 0; i < nqe; i++)
+      if (q_idx[i] < 0 || q_idx[i] >= nq) {
+        set_err("orbm_match_groups: q_idx out of range");
+        return -2;
+      }
+    for (int i = 0; i < nte; i++)
+      if (t_idx[i] < 0 || t_idx[i] >= nt) {
+        set_err("orbm_match_groups: t_idx out of range");
+        return -2;
+      }
+  }
+  hipStream_t s = h->stream;
+  if (h->dq.ensure((size_t)nq * 32 + 32) || h->dt.ensure((size_t)nt * 32 + 32) || h->topk.ensure((size_t)(nqe + 1) * kTopK) ||
+      h->nvalid.ensure(nqe + 1) || h->binOf.ensure(nq + 1) || h->mq.ensure(nq + 1) || h->mt.ensure(nt + 1) || h->nm.ensure(1) ||
+      h->qa.ensure(nq + 1) || h->ta.ensure(nt + 1) || h->dqv.ensure(nq + 1) || h->dtv.ensure(nt + 1) || h->qoff.ensure(ngroups + 2) ||
+      h->toff.ensure(ngroups + 2) || h->qidx.ensure(nqe + 1) || h->tidx.ensure(nte + 1))
+    return -3;
+  auto up = [&](void* d, const void* src, size_t bytes) -> hipError_t {
+    return bytes ? hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, s) : hipSuccess;
+  };
+  HIP_TRYM(up(h->dq.p, q, (size_t)nq * 32));
+  HIP_TRYM(up(h->dt.p, t, (size_t)nt * 32));
+  if (q_angle) HIP_TRYM(up(h->qa.p, q_angle, (size_t)nq * 4));
+  if (t_angle) HIP_TRYM(up(h->ta.p, t_angle, (size_t)nt * 4));
+  if (q_valid) HIP_TRYM(up(h->dqv.p, q_valid, nq));
+  if (t_valid) HIP_TRYM(up(h->dtv.p, t_valid, nt));
+  if (grouped) {
+    HIP_TRYM(up(h->qoff.p, q_off, (size_t)(ngroups + 1) * 4));
+    HIP_TRYM(up(h->toff.p, t_off, (size_t)(ngroups + 1) * 4));
+    HIP_TRYM(up(h->qidx.p, q_idx, (size_t)nqe * 4));
+    HIP_TRYM(up(h->tidx.p, t_idx, (size_t)nte * 4));
+  }
+  GroupArgs a;
+  memset(&a, 0, sizeof(a));
+  a.q = h->dq.p, a.t = h->dt.p, a.nq = nq, a.nt = nt, a.ngroups = ngroups, a.nqe = nqe;
+  a.q_off = grouped ? h->qoff.p : nullptr, a.q_idx = grouped ? h->qidx.p : nullptr;
+  a.t_off = grouped ? h->toff.p : nullptr, a.t_idx = grouped ? h->tidx.p : nullptr;
+  a.q_valid = q_valid ? h->dqv.p : nullptr, a.t_valid = t_valid ? h->dtv.p : nullptr;
+  a.q_angle = h->qa.p, a.t_angle = h->ta.p, a.q_astride = 1, a.t_astride = 1;
+  a.th = th, a.strict_lt = strict_lt, a.check_ori = check_ori, a.ratio = ratio;
+  a.topk = h->topk.p, a.nvalid = h->nvalid.p, a.binOf = h->binOf.p;
+  a.match_t_of_q = h->mq.p, a.match_q_of_t = h->mt.p, a.nmatches = h->nm.p;
+  int rc = launch_groups(h, a, nq, s);
+  if (rc) return rc;
+  int nm = 0;
+  HIP_TRYM(hipMemcpyAsync(&nm, h->nm.p, 4, hipMemcpyDeviceToHost, s));
+  if (match_t_of_q && nq) HIP_TRYM(hipMemcpyAsync(match_t_of_q, h->mq.p, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
+  if (match_q_of_t && nt) HIP_TRYM(hipMemcpyAsync(match_q_of_t, h->mt.p, (size_t)nt * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRYM(hipStreamSynchronize(s));
+  return nm;
+}
+
+int orbm_match_bruteforce_device(orbm_t* h, const uint8_t* d_q, const orbx_keypoint_t* d_q_kp, const int* d_nq, int cap_q,
+                                 const uint8_t* d_t, const orbx_keypoint_t* d_t_kp, const int* d_nt, int cap_t, int th, int strict_lt,
+                                 float ratio, int check_ori, int* d_match_t_of_q, int* d_nmatches, void* stream) {
+  if (!h || !d_q || !d_t || !d_nq || !d_nt || !d_match_t_of_q || !d_nmatches || cap_q <= 0 || cap_t <= 0 || cap_t > kMaxTrain) {
+    set_err("orbm_match_bruteforce_device: bad arguments");
+    return -2;
+  }
+  if (check_ori && (!d_q_kp || !d_t_kp)) {
+    set_err("orbm_match_bruteforce_device: check_ori needs the keypoint arrays");
+    return -2;
+  }
+  HIP_TRYM(hipSetDevice(h->device));
+  if (h->topk.ensure((size_t)(cap_q + 1) * kTopK) || h->nvalid.ensure(cap_q + 1) || h->binOf.ensure(cap_q + 1) || h->mt.ensure(cap_t + 1))
+    return -3;
+  GroupArgs a;
+  memset(&a, 0, sizeof(a));
+  a.q = d_q, a.t = d_t, a.d_nq = d_nq, a.d_nt = d_nt, a.nq = cap_q, a.nt = cap_t, a.ngroups = 1, a.nqe = cap_q;
+  a.q_angle = d_q_kp ? &d_q_kp->angle : nullptr, a.t_angle = d_t_kp ? &d_t_kp->angle : nullptr;
+  a.q_astride = a.t_astride = sizeof(orbx_keypoint_t) / 4;
+  a.th = th, a.strict_lt = strict_lt, a.check_ori = check_ori, a.ratio = ratio;
+  a.topk = h->topk.p, a.nvalid = h->nvalid.p, a.binOf = h->binOf.p;
+  a.match_t_of_q = d_match_t_of_q, a.match_q_of_t = h->mt.p, a.nmatches = d_nmatches;
+  return launch_groups(h, a, cap_q, stream ? (hipStream_t)stream : h->stream);
+}
+
+int orbm_match_pairs_device(orbm_t* h, const uint8_t* d_desc, const orbx_keypoint_t* d_kps, const int* d_counts, int cap,
+                            const int* d_pairs, int npairs, int th, int strict_lt, float ratio, int check_ori, int* d_match_t_of_q,
+                            int* d_nmatches, void* stream) {
+  if (!h || !d_desc || !d_counts || !d_pairs || !d_match_t_of_q || !d_nmatches || cap <= 0 || cap > kMaxTrain || npairs < 0) {
+    set_err("orbm_match_pairs_device: bad arguments");
+    return -2;
+  }
+  if (check_ori && !d_kps) {
+    set_err("orbm_match_pairs_device: check_ori needs the keypoint array");
+    return -2;
+  }
+  if (npairs == 0) return 0;
+  HIP_TRYM(hipSetDevice(h->device));
+  const size_t np = (size_t)npairs * cap;
+  if (h->topk.ensure(np * kTopK) || h->nvalid.ensure(np) || h->binOf.ensure(np) || h->mt.ensure(np)) return -3;
+  GroupArgs a;
+  memset(&a, 0, sizeof(a));
+  a.q = d_desc, a.t = d_desc, a.nq = cap, a.nt = cap, a.ngroups = 1, a.nqe = cap;
+  a.q_angle = d_kps ? &d_kps->angle : nullptr, a.t_angle = a.q_angle;
+  a.q_astride = a.t_astride = sizeof(orbx_keypoint_t) / 4;
+  a.th = th, a.strict_lt = strict_lt, a.check_ori = check_ori, a.ratio = ratio;
+  a.topk = h->topk.p, a.nvalid = h->nvalid.p, a.binOf = h->binOf.p;
+  a.match_t_of_q = d_match_t_of_q, a.match_q_of_t = h->mt.p, a.nmatches = d_nmatches;
+  a.pairs = d_pairs, a.counts = d_counts, a.cap = cap;
+  return launch_groups(h, a, cap, stream ? (hipStream_t)stream : h->stream, npairs);
+}
+
+int orbm_match_window(orbm_t* h, const uint8_t* d1, const orbx_keypoint_t* kp1, int n1, const uint8_t* d2, const orbx_keypoint_t* kp2,
+                      int n2, float* prev_matched, float min_x, float max_x, float min_y, float max_y, int window, int th, float ratio,
+                      int check_ori, int* matches12) {
+  if (!h || n1 < 0 || n2 < 0 || !matches12 || (n1 > 0 && (!d1 || !kp1 || !prev_matched)) || (n2 > 0 && (!d2 || !kp2)) ||
+      !(max_x > min_x) || !(max_y > min_y)) {
+    set_err("orbm_match_window: bad arguments");
+    return -2;
+  }
+  if (n2 > kMaxTrainW) {
+    set_err("orbm_match_window: more than 16384 train features");
+    return -2;
+  }
+  HIP_TRYM(hipSetDevice(h->device));
+  // Frame::AssignFeaturesToGrid / PosInGrid (src/Frame.cc:524-553, 867-877): candidate generator, host side
+  // (SURVEY.md section 8(a) A14).  Scan order of GetFeaturesInArea = cells (ix, iy) ascending, insertion order inside.
+  const float      gwInv = static_cast<float>(kGridCols) / (max_x - min_x);
+  const float      ghInv = static_cast<float>(kGridRows) / (max_y - min_y);
+  std::vector<int> cellCount(kGridCols * kGridRows + 1, 0), cellOf(n2, -1);
+  for (int i = 0; i < n2; i++) {
+    const int posX = (int)std::round((kp2[i].x - min_x) * gwInv);
+    const int posY = (int)std::round((kp2[i].y - min_y) * ghInv);
+    if (posX < 0 || posX >= kGridCols || posY < 0 || posY >= kGridRows) continue;
+    if (kp2[i].octave != 0) continue;  // only level-0 queries exist (:688) and they ask for level 0 only (:692-693)
+    cellOf[i] = posX * kGridRows + posY;
+    cellCount[cellOf[i] + 1]++;
+  }
+  for (int c = 0; c < kGridCols * kGridRows; c++) cellCount[c + 1] += cellCount[c];
+  const int            ng = cellCount[kGridCols * kGridRows];
+  std::vector<int>     gidx(ng + 1);
+  std::vector<uint8_t> gcx(ng + 1), gcy(ng + 1);
+  {
+    std::vector<int> fill(cellCount.begin(), cellCount.end() - 1);
+    for (int i = 0; i < n2; i++)
+      if (cellOf[i] >= 0) {
+        const int p = fill[cellOf[i]]++;
+        gidx[p]     = i;
+        gcx[p]      = (uint8_t)(cellOf[i] / kGridRows);
+        gcy[p]      = (uint8_t)(cellOf[i] % kGridRows);
+      }
+  }
+  hipStream_t s = h->stream;
+  if (h->dq.ensure((size_t)n1 * 32 + 32) || h->dt.ensure((size_t)n2 * 32 + 32) || h->kp1.ensure(n1 + 1) || h->kp2.ensure(n2 + 1) ||
+      h->gidx.ensure(ng + 1) || h->gcx.ensure(ng + 1) || h->gcy.ensure(ng + 1) || h->prev.ensure((size_t)2 * n1 + 2) ||
+      h->topk.ensure((size_t)(n1 + 1) * kTopK) || h->nvalid.ensure(n1 + 1) || h->binOf.ensure(n1 + 1) || h->mq.ensure(n1 + 1) ||
+      h->mt.ensure(n2 + 1) || h->nm.ensure(1))
+    return -3;
+  auto up = [&](void* d, const void* src, size_t bytes) -> hipError_t {
+    return bytes ? hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, s) : hipSuccess;
+  };
+  HIP_TRYM(up(h->dq.p, d1, (size_t)n1 * 32));
+  HIP_TRYM(up(h->dt.p, d2, (size_t)n2 * 32));
+  HIP_TRYM(up(h->kp1.p, kp1, (size_t)n1 * sizeof(orbx_keypoint_t)));
+  HIP_TRYM(up(h->kp2.p, kp2, (size_t)n2 * sizeof(orbx_keypoint_t)));
+  HIP_TRYM(up(h->gidx.p, gidx.data(), (size_t)ng * 4));
+  HIP_TRYM(up(h->gcx.p, gcx.data(), ng));
+  HIP_TRYM(up(h->gcy.p, gcy.data(), ng));
+  HIP_TRYM(up(h->prev.p, prev_matched, (size_t)n1 * 8));
+  WindowArgs a;
+  memset(&a, 0, sizeof(a));
+  a.d1 = h->dq.p, a.d2 = h->dt.p, a.kp1 = h->kp1.p, a.kp2 = h->kp2.p, a.n1 = n1, a.n2 = n2, a.ng = ng;
+  a.g_idx = h->gidx.p, a.g_cx = h->gcx.p, a.g_cy = h->gcy.p, a.prev = h->prev.p;
+  a.minX = min_x, a.minY = min_y, a.gwInv = gwInv, a.ghInv = ghInv, a.r = (float)window;
+  a.th = th, a.check_ori = check_ori, a.ratio = ratio;
+  a.topk = h->topk.p, a.nvalid = h->nvalid.p, a.m12 = h->mq.p, a.m21 = h->mt.p, a.binOf = h->binOf.p, a.nmatches = h->nm.p;
+  if (n1 > 0) hipLaunchKernelGGL(k_window_topk, dim3((n1 + 3) / 4), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_window_resolve, dim3(1), dim3(64), 0, s, a);
+  HIP_TRYM(hipGetLastError());
+  int nm = 0;
+  HIP_TRYM(hipMemcpyAsync(&nm, h->nm.p, 4, hipMemcpyDeviceToHost, s));
+  if (n1) {
+    HIP_TRYM(hipMemcpyAsync(matches12, h->mq.p, (size_t)n1 * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRYM(hipMemcpyAsync(prev_matched, h->prev.p, (size_t)n1 * 8, hipMemcpyDeviceToHost, s));
+  }
+  HIP_TRYM(hipStreamSynchronize(s));
+  return nm;
+}
+
+}  // extern "C"

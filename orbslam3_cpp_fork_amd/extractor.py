@@ -1,0 +1,150 @@
+"""Host-side mirror of ORB_SLAM3::ORBextractor (reference include/ORBextractor.h:41-119) over the C ABI.
+
+Same constructor arguments, same call convention (`operator()(image, mask, keypoints, descriptors,
+vLappingArea)` -> returns monoIndex, fills keypoints/descriptors), same getters, same error behaviour
+(-1 on an empty image).  The compute runs in the HIP kernels of liborbx.so; nothing here computes.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import KP_DTYPE, OrbxError, check, ptr
+
+
+class ORBextractor:
+    def __init__(self, nfeatures=1000, scaleFactor=1.2, nlevels=8, iniThFAST=20, minThFAST=7, device=0):
+        self._h = C.c_void_p()
+        L = _lib.lib()
+        check(L.orbx_create(C.byref(self._h), nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, device), "orbx_create")
+        self.nfeatures, self.nlevels, self.device = nfeatures, nlevels, device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().orbx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- include/ORBextractor.h:63-85
+    def GetLevels(self):
+        return _lib.lib().orbx_get_levels(self._h)
+
+    def _tables(self):
+        t = [np.zeros(self.nlevels, np.float32) for _ in range(4)]
+        _lib.lib().orbx_get_scale_tables(self._h, *[ptr(a) for a in t])
+        return t
+
+    def GetScaleFactor(self):
+        return float(self._tables()[0][1]) if self.nlevels > 1 else 1.0
+
+    def GetScaleFactors(self):
+        return self._tables()[0]
+
+    def GetInverseScaleFactors(self):
+        return self._tables()[1]
+
+    def GetScaleSigmaSquares(self):
+        return self._tables()[2]
+
+    def GetInverseScaleSigmaSquares(self):
+        return self._tables()[3]
+
+    def features_per_level(self):
+        a = np.zeros(self.nlevels, np.int32)
+        _lib.lib().orbx_get_features_per_level(self._h, ptr(a))
+        return a
+
+    def max_keypoints(self, rows, cols):
+        return check(_lib.lib().orbx_max_keypoints(self._h, rows, cols), "orbx_max_keypoints")
+
+    # ---- operator() (include/ORBextractor.h:55-61)
+    def __call__(self, image, mask=None, vLappingArea=(0, 0)):
+        """Returns (monoIndex, keypoints[KP_DTYPE], descriptors[n, 32] uint8).  `mask` is ignored, as in the reference."""
+        if image is None or image.size == 0:
+            return -1, np.zeros(0, KP_DTYPE), np.zeros((0, 32), np.uint8)
+        img = np.asarray(image)
+        if img.dtype != np.uint8 or img.ndim != 2:
+            raise OrbxError("image must be 8-bit single channel (assert(image.type() == CV_8UC1))")
+        if img.strides[1] != 1:
+            img = np.ascontiguousarray(img)
+        rows, cols = img.shape
+        cap = self.max_keypoints(rows, cols)
+        kps = np.zeros(cap, KP_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        n = C.c_int(0)
+        rc = check(
+            _lib.lib().orbx_extract(self._h, ptr(img), rows, cols, img.strides[0], int(vLappingArea[0]), int(vLappingArea[1]), ptr(kps), ptr(desc), cap, C.byref(n)),
+            "orbx_extract",
+        )
+        return rc, kps[: n.value].copy(), desc[: n.value].copy()
+
+    def extract_batch_device(self, d_imgs, nframes, rows, cols, step, frame_stride, d_kps, d_desc, d_counts, cap, vLappingArea=(0, 0), stream=None):
+        """Enqueue extraction of `nframes` device-resident frames; outputs stay on the device.  Pointers may be
+        torch tensors (data_ptr is taken) or raw ints; `stream` is a hipStream_t value or None."""
+        return check(
+            _lib.lib().orbx_extract_batch_device(
+                self._h, ptr(d_imgs), nframes, rows, cols, step, frame_stride, int(vLappingArea[0]), int(vLappingArea[1]), ptr(d_kps), ptr(d_desc), ptr(d_counts), cap,
+                C.c_void_p(stream) if stream else None,
+            ),
+            "orbx_extract_batch_device",
+        )
+
+    # ---- mvImagePyramid (include/ORBextractor.h:87)
+    def _level(self, fn, frame, level):
+        r, c = C.c_int(0), C.c_int(0)
+        check(fn(self._h, frame, level, None, 0, C.byref(r), C.byref(c)), "level query")
+        out = np.zeros((r.value, c.value), np.uint8)
+        check(fn(self._h, frame, level, ptr(out), out.strides[0], C.byref(r), C.byref(c)), "level copy")
+        return out
+
+    def pyramid_level(self, level, frame=0):
+        return self._level(_lib.lib().orbx_pyramid_level, frame, level)
+
+    @property
+    def mvImagePyramid(self):
+        return [self.pyramid_level(l) for l in range(self.nlevels)]
+
+    # ---- parity hooks
+    def debug_blurred_level(self, level, frame=0):
+        return self._level(_lib.lib().orbx_debug_blurred_level, frame, level)
+
+    def _packed(self, fn, frame, level, cap):
+        out = np.zeros(cap, np.uint32)
+        n = check(fn(self._h, frame, level, ptr(out), cap), "debug list")
+        out = out[:n]
+        return (out & 0xFFF).astype(np.int32), ((out >> 12) & 0xFFF).astype(np.int32), (out >> 24).astype(np.int32)
+
+    def debug_level_candidates(self, level, frame=0, cap=1 << 20):
+        return self._packed(_lib.lib().orbx_debug_level_candidates, frame, level, cap)
+
+    def debug_level_keypoints(self, level, frame=0, cap=1 << 16):
+        return self._packed(_lib.lib().orbx_debug_level_keypoints, frame, level, cap)
+
+    def debug_octree_device(self, xs, ys, resp, W, H, N):
+        cand = (np.asarray(xs, np.uint32) | (np.asarray(ys, np.uint32) << 12) | (np.asarray(resp, np.uint32) << 24)).astype(np.uint32)
+        out = np.zeros(max(N + 3, 4 * max(1, int(round(W / H)))) + 64, np.uint32)
+        cnt = C.c_int(0)
+        check(_lib.lib().orbx_debug_octree_device(self._h, ptr(cand), len(cand), W, H, N, ptr(out), C.byref(cnt)), "octree_device")
+        return out[: cnt.value].copy()
+
+    def set_profiling(self, enable=True):
+        _lib.lib().orbx_set_profiling(self._h, int(enable))
+
+    def stage_ms(self):
+        ms = np.zeros(_lib.NUM_STAGES, np.float32)
+        check(_lib.lib().orbx_get_stage_ms(self._h, ptr(ms)), "orbx_get_stage_ms")
+        return dict(zip(_lib.STAGE_NAMES, ms.tolist()))
+
+
+def octree_host_model(xs, ys, resp, W, H, N):
+    """Host build of the kernel's quadtree core (octree_core.h) -- CPU tests only."""
+    cand = (np.asarray(xs, np.uint32) | (np.asarray(ys, np.uint32) << 12) | (np.asarray(resp, np.uint32) << 24)).astype(np.uint32)
+    out = np.zeros(max(N + 3, 4 * max(1, int(round(W / H)))) + 64, np.uint32)
+    cnt = C.c_int(0)
+    rc = _lib.lib().orbx_debug_octree_host(ptr(cand), len(cand), W, H, N, ptr(out), C.byref(cnt))
+    return rc, out[: cnt.value].copy()

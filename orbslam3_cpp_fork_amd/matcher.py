@@ -1,0 +1,139 @@
+"""Host-side mirror of ORB_SLAM3::ORBmatcher (reference include/ORBmatcher.h:35-148) over the C ABI.
+
+The reference's methods take Frame / KeyFrame objects; here they take the arrays those objects hold
+(descriptors N x 32 u8, keypoint records, DBoW2 FeatureVectors as {node_id: [feature indices]} dicts, MapPoint
+validity masks).  Constants, thresholds, the greedy claim order and the rotation check are the reference's.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import KP_DTYPE, check, ptr
+
+
+def flatten_feature_vectors(fv_q, fv_t):
+    """Merge-walk of two DBoW2::FeatureVector (std::map<NodeId, vector<uint>>) as SearchByBoW does
+    (src/ORBmatcher.cc:259-399): only nodes present in both, ascending node id."""
+    q_off, q_idx, t_off, t_idx = [0], [], [0], []
+    for node in sorted(set(fv_q).intersection(fv_t)):
+        q_idx.extend(fv_q[node])
+        t_idx.extend(fv_t[node])
+        q_off.append(len(q_idx))
+        t_off.append(len(t_idx))
+    return (np.asarray(q_off, np.int32), np.asarray(q_idx, np.int32), np.asarray(t_off, np.int32), np.asarray(t_idx, np.int32))
+
+
+class ORBmatcher:
+    TH_HIGH = 100  # src/ORBmatcher.cc:30
+    TH_LOW = 50  # src/ORBmatcher.cc:31
+    HISTO_LENGTH = 30  # src/ORBmatcher.cc:32
+
+    def __init__(self, nnratio=0.6, checkOri=True, device=0):
+        self.mfNNratio = float(nnratio)
+        self.mbCheckOrientation = bool(checkOri)
+        self._h = C.c_void_p()
+        check(_lib.lib().orbm_create(C.byref(self._h), device), "orbm_create")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().orbm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def DescriptorDistance(a, b):
+        """src/ORBmatcher.cc:2075-2089"""
+        a = np.ascontiguousarray(a, np.uint8)
+        b = np.ascontiguousarray(b, np.uint8)
+        return _lib.lib().orbm_hamming(ptr(a), ptr(b))
+
+    @staticmethod
+    def ComputeThreeMaxima(counts):
+        """src/ORBmatcher.cc:2038-2071 on bin sizes."""
+        counts = np.ascontiguousarray(counts, np.int32)
+        i1, i2, i3 = C.c_int(-1), C.c_int(-1), C.c_int(-1)
+        _lib.lib().orbm_three_maxima(ptr(counts), len(counts), C.byref(i1), C.byref(i2), C.byref(i3))
+        return i1.value, i2.value, i3.value
+
+    def _groups(self, q, t, q_angle, t_angle, groups, q_valid, t_valid, th, strict_lt):
+        q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32)
+        t = np.ascontiguousarray(t, np.uint8).reshape(-1, 32)
+        nq, nt = len(q), len(t)
+        qa = np.ascontiguousarray(q_angle if q_angle is not None else np.zeros(nq), np.float32)
+        ta = np.ascontiguousarray(t_angle if t_angle is not None else np.zeros(nt), np.float32)
+        qv = None if q_valid is None else np.ascontiguousarray(q_valid, np.uint8)
+        tv = None if t_valid is None else np.ascontiguousarray(t_valid, np.uint8)
+        if groups is None:
+            ng, qo, qi, to, ti = 1, None, None, None, None
+        else:
+            qo, qi, to, ti = (np.ascontiguousarray(a, np.int32) for a in groups)
+            ng = len(qo) - 1
+            if ng == 0:
+                return 0, np.full(nq, -1, np.int32), np.full(nt, -1, np.int32)
+        mq, mt = np.zeros(nq, np.int32), np.zeros(nt, np.int32)
+        n = check(
+            _lib.lib().orbm_match_groups(
+                self._h, ptr(q), nq, ptr(t), nt, ng, ptr(qo), ptr(qi), ptr(to), ptr(ti), ptr(qv), ptr(tv), ptr(qa), ptr(ta), th, int(strict_lt),
+                self.mfNNratio, int(self.mbCheckOrientation), ptr(mq), ptr(mt),
+            ),
+            "orbm_match_groups",
+        )
+        return n, mq, mt
+
+    def SearchByBoW(self, kf_desc, kf_angle, kf_featvec, kf_has_mappoint, f_desc, f_angle, f_featvec):
+        """SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches) (src/ORBmatcher.cc:237-421, F.Nleft == -1).
+        Returns (nmatches, match_kf_of_f[F.N]) -- the KeyFrame feature whose MapPoint each Frame feature received, -1 = NULL."""
+        groups = None if kf_featvec is None else flatten_feature_vectors(kf_featvec, f_featvec)
+        n, mq, mt = self._groups(kf_desc, f_desc, kf_angle, f_angle, groups, kf_has_mappoint, None, self.TH_LOW, False)
+        return n, mt
+
+    def SearchByBoW_KF(self, desc1, angle1, featvec1, has_mp1, desc2, angle2, featvec2, has_mp2):
+        """SearchByBoW(KeyFrame*, KeyFrame*, vpMatches12) (src/ORBmatcher.cc:784-914): `< TH_LOW`, both sides need MapPoints.
+        Returns (nmatches, match_2_of_1[N1])."""
+        groups = None if featvec1 is None else flatten_feature_vectors(featvec1, featvec2)
+        n, mq, mt = self._groups(desc1, desc2, angle1, angle2, groups, has_mp1, has_mp2, self.TH_LOW, True)
+        return n, mq
+
+    def SearchForInitialization(self, kps1, desc1, kps2, desc2, vbPrevMatched, bounds, windowSize=10):
+        """src/ORBmatcher.cc:666-782.  kps are undistorted keypoints (KP_DTYPE); bounds = (mnMinX, mnMaxX, mnMinY, mnMaxY).
+        Returns (nmatches, vnMatches12, updated vbPrevMatched)."""
+        kps1 = np.ascontiguousarray(kps1, KP_DTYPE)
+        kps2 = np.ascontiguousarray(kps2, KP_DTYPE)
+        d1 = np.ascontiguousarray(desc1, np.uint8).reshape(-1, 32)
+        d2 = np.ascontiguousarray(desc2, np.uint8).reshape(-1, 32)
+        pm = np.ascontiguousarray(vbPrevMatched, np.float32).reshape(-1, 2).copy()
+        m12 = np.zeros(len(kps1), np.int32)
+        n = check(
+            _lib.lib().orbm_match_window(
+                self._h, ptr(d1), ptr(kps1), len(kps1), ptr(d2), ptr(kps2), len(kps2), ptr(pm), float(bounds[0]), float(bounds[1]), float(bounds[2]), float(bounds[3]),
+                int(windowSize), self.TH_LOW, self.mfNNratio, int(self.mbCheckOrientation), ptr(m12),
+            ),
+            "orbm_match_window",
+        )
+        return n, m12, pm
+
+    def match_bruteforce_device(self, d_q, d_q_kp, d_nq, cap_q, d_t, d_t_kp, d_nt, cap_t, d_match, d_nmatches, th=None, strict_lt=False, stream=None):
+        """Device-resident brute-force SearchByBoW (one group): enqueue only."""
+        return check(
+            _lib.lib().orbm_match_bruteforce_device(
+                self._h, ptr(d_q), ptr(d_q_kp), ptr(d_nq), cap_q, ptr(d_t), ptr(d_t_kp), ptr(d_nt), cap_t, self.TH_LOW if th is None else th, int(strict_lt),
+                self.mfNNratio, int(self.mbCheckOrientation), ptr(d_match), ptr(d_nmatches), C.c_void_p(stream) if stream else None,
+            ),
+            "orbm_match_bruteforce_device",
+        )
+
+    def match_pairs_device(self, d_desc, d_kps, d_counts, cap, d_pairs, npairs, d_match, d_nmatches, th=None, strict_lt=False, stream=None):
+        """Brute-force SearchByBoW for `npairs` (query frame, train frame) pairs of one extraction batch: enqueue only."""
+        return check(
+            _lib.lib().orbm_match_pairs_device(
+                self._h, ptr(d_desc), ptr(d_kps), ptr(d_counts), cap, ptr(d_pairs), npairs, self.TH_LOW if th is None else th, int(strict_lt),
+                self.mfNNratio, int(self.mbCheckOrientation), ptr(d_match), ptr(d_nmatches), C.c_void_p(stream) if stream else None,
+            ),
+            "orbm_match_pairs_device",
+        )

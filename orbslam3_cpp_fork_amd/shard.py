@@ -1,0 +1,67 @@
+"""Multi-GPU sharding of the extraction path.
+
+ORBextractor::operator() depends only on its own image (reference src/ORBextractor.cc:1052-1138), so the
+path shards by camera/frame with no data-path collective; the one exchange step is a gather of the fixed-
+capacity per-frame results to rank 0 (the consumer: Tracking runs in one process in the reference).  One
+process per GPU, torch.distributed ("nccl" == RCCL on ROCm; "gloo" in the CPU tests).
+
+Record layout gathered per rank, all uint8 views of the extractor's own output buffers:
+    counts  [B][2] int32   (n, monoIndex)
+    kps     [B][cap] 28-byte cv::KeyPoint records
+    desc    [B][cap][32] uint8
+~60 KB per frame at 1000 features: the gather is latency-bound, not xGMI-bandwidth-bound, so it is issued
+as ONE flat byte tensor per rank per step (a single collective instead of three).
+"""
+import numpy as np
+
+
+def camera_of_rank(rank, world, cameras_per_rank=1, slot=0):
+    """Camera index owned by `rank`: cameras are dealt round-robin, camera c -> rank c % world."""
+    return slot * world + rank
+
+
+def cameras_of_rank(rank, world, n_cameras):
+    return [c for c in range(n_cameras) if c % world == rank]
+
+
+def record_bytes(B, cap):
+    return B * 2 * 4 + B * cap * 28 + B * cap * 32
+
+
+class RecordGather:
+    """Packs (counts, keypoints, descriptors) of one step into one byte tensor and gathers it on rank 0."""
+
+    def __init__(self, B, cap, device, world, rank, dst=0):
+        import torch
+
+        self.B, self.cap, self.world, self.rank, self.dst = B, cap, world, rank, dst
+        self.nbytes = record_bytes(B, cap)
+        self.send = torch.empty(self.nbytes, dtype=torch.uint8, device=device)
+        self.recv = [torch.empty(self.nbytes, dtype=torch.uint8, device=device) for _ in range(world)] if rank == dst else None
+        self._o1 = B * 2 * 4
+        self._o2 = self._o1 + B * cap * 28
+
+    def pack(self, d_kps, d_desc, d_cnt):
+        import torch
+
+        self.send[: self._o1].copy_(d_cnt.reshape(-1).view(torch.uint8))
+        self.send[self._o1: self._o2].copy_(d_kps.reshape(-1).view(torch.uint8))
+        self.send[self._o2:].copy_(d_desc.reshape(-1))
+        return self.send
+
+    def __call__(self, d_kps, d_desc, d_cnt):
+        import torch.distributed as dist
+
+        self.pack(d_kps, d_desc, d_cnt)
+        dist.gather(self.send, self.recv, dst=self.dst)
+        return self.recv
+
+    def unpack(self, buf):
+        """buf: one rank's byte tensor (on any device) -> (counts[B,2] int32, kps[B,cap] KP_DTYPE, desc[B,cap,32])."""
+        from ._lib import KP_DTYPE
+
+        a = buf.cpu().numpy()
+        cnt = a[: self._o1].view(np.int32).reshape(self.B, 2)
+        kps = a[self._o1: self._o2].view(KP_DTYPE).reshape(self.B, self.cap)
+        desc = a[self._o2:].reshape(self.B, self.cap, 32)
+        return cnt, kps, desc

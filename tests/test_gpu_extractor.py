@@ -1,0 +1,137 @@
+"""GPU parity tests (run with -m gpu on an MI355X): HIP path through the C ABI vs the CPU oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu_ex():
+    from orbslam3_cpp_fork_amd.extractor import ORBextractor
+
+    ex = ORBextractor(1000, 1.2, 8, 20, 7)
+    yield ex
+    ex.close()
+
+
+def _unpack(xs, ys, rs):
+    return list(zip(xs.tolist(), ys.tolist(), rs.tolist()))
+
+
+def assert_same_output(ref, got, what=""):
+    rc0, k0, d0 = ref
+    rc1, k1, d1 = got
+    assert rc0 == rc1, (what, rc0, rc1)
+    assert len(k0) == len(k1), (what, len(k0), len(k1))
+    for f in k0.dtype.names:
+        a, b = k0[f], k1[f]
+        assert (a.view(np.uint32) == b.view(np.uint32)).all(), (what, f, int((a != b).sum()))
+    assert (d0 == d1).all(), (what, "descriptor bits differing", int(np.unpackbits(d0 ^ d1).sum()))
+
+
+def test_stagewise_vga(oracle, gpu_ex, vga_frame):
+    """Config 2 (640x480, 8 levels, 1000 features): every stage bit-exact vs the oracle."""
+    oex = oracle.OracleExtractor(1000, 1.2, 8, 20, 7)
+    ref = oex(vga_frame, (0, 0))
+    got = gpu_ex(vga_frame, None, (0, 0))
+    for l in range(8):
+        assert (gpu_ex.pyramid_level(l) == oex.pyramid_level(l)).all(), "pyramid level %d" % l
+    for l in range(8):
+        assert (gpu_ex.debug_blurred_level(l) == oex.blurred_level(l)).all(), "blur level %d" % l
+    for l in range(8):
+        assert _unpack(*gpu_ex.debug_level_candidates(l)) == _unpack(*oex.level_candidates(l)), "FAST candidates level %d" % l
+    for l in range(8):
+        kx, ky, kr = gpu_ex.debug_level_keypoints(l)
+        ok = oex.level_keypoints(l)
+        assert (kx + 16).tolist() == ok["x"].astype(int).tolist() and (ky + 16).tolist() == ok["y"].astype(int).tolist(), "octree level %d" % l
+        assert kr.tolist() == ok["response"].astype(int).tolist()
+    assert_same_output(ref, got, "vga natural order")
+    assert len(got[1]) > 900
+
+
+@pytest.mark.parametrize("lap", [(0, 0), (0, 1000), (200, 400)])
+def test_lapping_order(oracle, gpu_ex, vga_frame, lap):
+    oex = oracle.OracleExtractor(1000, 1.2, 8, 20, 7)
+    assert_same_output(oex(vga_frame, lap), gpu_ex(vga_frame, None, lap), "lap %s" % (lap,))
+
+
+@pytest.mark.parametrize(
+    "h,w,nf",
+    [(480, 752, 1000), (350, 600, 1000), (376, 1241, 2000), (480, 752, 5000), (240, 320, 500), (1080, 1920, 1000)],
+)
+def test_other_configs(oracle, h, w, nf):
+    from orbslam3_cpp_fork_amd import synth
+    from orbslam3_cpp_fork_amd.extractor import ORBextractor
+
+    img = synth.make_frame(h, w, camera_idx=3, frame_idx=w % 17)
+    oex = oracle.OracleExtractor(nf, 1.2, 8, 20, 7)
+    gex = ORBextractor(nf, 1.2, 8, 20, 7)
+    lap = (0, 1000) if nf != 2000 else (0, 0)
+    assert_same_output(oex(img, lap), gex(img, None, lap), "%dx%d/%d" % (w, h, nf))
+    gex.close()
+
+
+def test_edge_inputs(oracle, gpu_ex):
+    from orbslam3_cpp_fork_amd import synth
+
+    # empty image -> -1 (src/ORBextractor.cc:1060-1062)
+    assert gpu_ex(np.zeros((0, 0), np.uint8))[0] == -1
+    # flat image: no corners at either threshold
+    rc, k, d = gpu_ex(np.full((480, 640), 128, np.uint8), None, (0, 0))
+    assert rc == 0 and len(k) == 0
+    # low-contrast image: exercises the minThFAST retry in most cells
+    img = (synth.make_frame(480, 640, 9, 9).astype(np.int32) // 6 + 100).astype(np.uint8)
+    oex = oracle.OracleExtractor(1000, 1.2, 8, 20, 7)
+    assert_same_output(oex(img, (0, 0)), gpu_ex(img, None, (0, 0)), "low contrast")
+    # noise image: thousands of candidates per level, quadtree under pressure
+    rng = np.random.default_rng(77)
+    img = rng.integers(0, 256, (480, 640), dtype=np.uint8)
+    assert_same_output(oex(img, (0, 0)), gpu_ex(img, None, (0, 0)), "noise")
+    # non-contiguous rows (step > cols)
+    big = synth.make_frame(500, 700, 1, 2)
+    view = big[10:490, 30:670]
+    assert_same_output(oex(view, (0, 0)), gpu_ex(view, None, (0, 0)), "strided view")
+
+
+def test_octree_device_random(oracle, gpu_ex):
+    rng = np.random.default_rng(123)
+    for trial in range(40):
+        W, H = int(rng.integers(100, 1300)), int(rng.integers(100, 700))
+        if round(np.float32(W) / np.float32(H)) < 1:
+            continue
+        n = int(rng.integers(0, 4000))
+        N = int(rng.choice([1, 17, 60, 217, 434, 1086]))
+        px, py = rng.integers(3, W - 3, n), rng.integers(3, H - 3, n)
+        key = rng.permutation(np.unique(py.astype(np.int64) * 4096 + px))
+        px, py = (key % 4096).astype(np.int32), (key // 4096).astype(np.int32)
+        rs = rng.integers(7, 40, len(px)).astype(np.int32)
+        n1, idx = oracle.distribute_octtree(px, py, rs, 16, 16 + W, 16, 16 + H, N)
+        out = gpu_ex.debug_octree_device(px, py, rs, W, H, N)
+        exp = px[idx].astype(np.uint32) | (py[idx].astype(np.uint32) << 12) | (rs[idx].astype(np.uint32) << 24)
+        assert len(out) == n1 and (out == exp).all(), trial
+
+
+def test_batch_device_matches_single(oracle, gpu_ex):
+    """The device-resident batch entry point yields, per frame, exactly the single-frame result."""
+    import torch
+
+    from orbslam3_cpp_fork_amd import synth
+    from orbslam3_cpp_fork_amd._lib import KP_DTYPE
+
+    B, h, w = 5, 480, 640
+    frames = np.stack([synth.make_frame(h, w, camera_idx=c) for c in range(B)])
+    d_imgs = torch.from_numpy(frames).cuda()
+    cap = gpu_ex.max_keypoints(h, w)
+    d_kps = torch.zeros((B, cap, 7), dtype=torch.float32, device="cuda")
+    d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
+    d_cnt = torch.zeros((B, 2), dtype=torch.int32, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    gpu_ex.extract_batch_device(d_imgs, B, h, w, w, h * w, d_kps, d_desc, d_cnt, cap, (0, 1000), stream=s)
+    torch.cuda.synchronize()
+    cnt = d_cnt.cpu().numpy()
+    oex = oracle.OracleExtractor(1000, 1.2, 8, 20, 7)
+    for f in range(B):
+        n, mono = int(cnt[f, 0]), int(cnt[f, 1])
+        k = d_kps[f, :n].cpu().numpy().view(KP_DTYPE).reshape(-1)
+        d = d_desc[f, :n].cpu().numpy()
+        assert_same_output(oex(frames[f], (0, 1000)), (mono, k, d), "batch frame %d" % f)

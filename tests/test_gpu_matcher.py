@@ -1,0 +1,114 @@
+"""GPU parity tests of the Hamming matcher (orbm_*) vs the CPU oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def synth():
+    from orbslam3_cpp_fork_amd import synth as s
+
+    return s
+
+
+def _mk(ratio, ori):
+    from orbslam3_cpp_fork_amd.matcher import ORBmatcher
+
+    return ORBmatcher(ratio, ori)
+
+
+def test_hamming_and_maxima(oracle, synth):
+    from orbslam3_cpp_fork_amd.matcher import ORBmatcher
+
+    d = synth.random_descriptors(64, 5)
+    for i in range(0, 64, 2):
+        assert ORBmatcher.DescriptorDistance(d[i], d[i + 1]) == oracle.hamming(d[i], d[i + 1])
+    assert ORBmatcher.DescriptorDistance(np.zeros(32, np.uint8), np.full(32, 255, np.uint8)) == 256
+    rng = np.random.default_rng(0)
+    for _ in range(50):
+        c = rng.integers(0, 12, 30).astype(np.int32)
+        assert ORBmatcher.ComputeThreeMaxima(c) == oracle.three_maxima(c)
+
+
+@pytest.mark.parametrize("nq,nt,flips,ratio", [(1000, 1000, 20, 0.7), (1000, 1000, 60, 0.9), (2000, 2000, 40, 0.75), (37, 5, 10, 0.6), (300, 3, 5, 0.9), (0, 10, 0, 0.7), (10, 0, 0, 0.7)])
+def test_bruteforce_planted(oracle, synth, nq, nt, flips, ratio):
+    rng = np.random.default_rng(nq * 7 + nt)
+    t = synth.random_descriptors(nt, 100 + nt)
+    if nq and nt:
+        src = rng.integers(0, nt, nq)
+        q = synth.planted_descriptors(t[src], 200 + nq, max_flips=flips)  # several queries may share a train row -> claim conflicts
+    else:
+        q = synth.random_descriptors(nq, 300)
+    qa = rng.uniform(0, 360, nq).astype(np.float32)
+    ta = rng.uniform(0, 360, nt).astype(np.float32)
+    if nq and nt:
+        ta[:] = 10.0
+        qa[: nq // 2] = 25.0  # two dominant rotation bins + noise
+    for strict in (False, True):
+        m = _mk(ratio, True)
+        n0, mq0, mt0 = oracle.match_groups(q, t, qa, ta, th=50, ratio=ratio, strict_lt=strict, check_ori=True)
+        n1, mq1, mt1 = m._groups(q, t, qa, ta, None, None, None, 50, strict)
+        assert n0 == n1 and (mq0 == mq1).all() and (mt0 == mt1).all()
+        m.close()
+
+
+def test_grouped_bow(oracle, synth):
+    """Flattened FeatureVector groups with MapPoint masks, both overloads (<= TH_LOW and < TH_LOW)."""
+    rng = np.random.default_rng(42)
+    nq = nt = 1200
+    t = synth.random_descriptors(nt, 1)
+    q = synth.planted_descriptors(t[rng.permutation(nt)[:nq]], 2, max_flips=55)
+    nodes = 90
+    fq = {i: [] for i in range(nodes)}
+    ft = {i: [] for i in range(0, nodes, 1)}
+    for i in range(nq):
+        fq[int(rng.integers(0, nodes))].append(i)
+    for i in range(nt):
+        ft[int(rng.integers(0, nodes))].append(i)
+    fq = {k: v for k, v in fq.items() if v and k % 7 != 3}
+    ft = {k: v for k, v in ft.items() if v and k % 5 != 2}
+    from orbslam3_cpp_fork_amd.matcher import flatten_feature_vectors
+
+    groups = flatten_feature_vectors(fq, ft)
+    qv = (rng.uniform(size=nq) < 0.8).astype(np.uint8)
+    tv = (rng.uniform(size=nt) < 0.9).astype(np.uint8)
+    qa = rng.choice([0.0, 14.9, 15.0, 100.0, 344.9, 345.0, 359.0], nq).astype(np.float32)
+    ta = np.zeros(nt, np.float32)
+    m = _mk(0.9, True)
+    for strict, tvv in ((False, None), (True, tv)):
+        n0, mq0, mt0 = oracle.match_groups(q, t, qa, ta, th=50, ratio=0.9, strict_lt=strict, check_ori=True, groups=groups, q_valid=qv, t_valid=tvv)
+        n1, mq1, mt1 = m._groups(q, t, qa, ta, groups, qv, tvv, 50, strict)
+        assert n0 == n1 and (mq0 == mq1).all() and (mt0 == mt1).all()
+    # big group forcing K-list exhaustion: many identical queries all fighting for the same few train rows
+    t2 = synth.random_descriptors(400, 9)
+    q2 = np.repeat(t2[:8], 40, axis=0)
+    n0, mq0, mt0 = oracle.match_groups(q2, t2, check_ori=False, ratio=0.99, th=100)
+    mm = _mk(0.99, False)
+    n1, mq1, mt1 = mm._groups(q2, t2, None, None, None, None, None, 100, False)
+    assert n0 == n1 and (mq0 == mq1).all() and (mt0 == mt1).all()
+
+
+def test_search_for_initialization(oracle, synth):
+    """Frames from the extractor oracle: level-0 windowed matching with re-assignment (config 1 plumbing)."""
+    frames = synth.make_stream(480, 752, 2, camera_idx=4)
+    oex = oracle.OracleExtractor(5000, 1.2, 8, 20, 7)
+    _, k1, d1 = oex(frames[0], (0, 1000))
+    _, k2, d2 = oex(frames[1], (0, 1000))
+    prev = np.stack([k1["x"], k1["y"]], 1).astype(np.float32)
+    bounds = (0.0, 752.0, 0.0, 480.0)
+    m = _mk(0.9, True)
+    for window in (100, 30):
+        n0, m0, p0 = oracle.match_window(d1, k1, d2, k2, prev, bounds, window=window, th=50, ratio=0.9, check_ori=True)
+        n1, m1, p1 = m.SearchForInitialization(k1, d1, k2, d2, prev, bounds, window)
+        assert n0 == n1 and (m0 == m1).all() and (p0 == p1).all()
+        assert n0 > 50
+    # adversarial: duplicated descriptors in F2 so that re-assignment and the vMatchedDistance skip fire
+    d2b = d2.copy()
+    k = min(len(d2b[::3]), len(d2b[1::3]))
+    d2b[: 3 * k: 3] = d2b[1: 3 * k: 3]
+    n0, m0, p0 = oracle.match_window(d1, k1, d2b, k2, prev, bounds, window=100, th=80, ratio=0.99, check_ori=False)
+    mm = _mk(0.99, False)
+    mm.TH_LOW = 80
+    n1, m1, p1 = mm.SearchForInitialization(k1, d1, k2, d2b, prev, bounds, 100)
+    assert n0 == n1 and (m0 == m1).all() and (p0 == p1).all()
