@@ -131,6 +131,10 @@ int orbm_match_pairs_device(orbm_t* h, const uint8_t* d_desc, const orbx_keypoin
                             const int* d_pairs, int npairs, int th, int strict_lt, float ratio, int check_ori, int* d_match_t_of_q,
                             int* d_nmatches, void* stream);
 
+/* Tuning hook for orbm_match_pairs_device: enable = 1 arms the counters {speculative rounds, exact rescans,
+ * 64-query chunks}; enable = 0 synchronises the device and copies them to out[3]. */
+int orbm_debug_counters(orbm_t* h, int enable, int* out);
+
 /* ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:666-782) including Frame::GetFeaturesInArea over
  * the 64 x 48 grid (src/Frame.cc:524-553, 788-877).  kp1 / kp2 are undistorted keypoints; prev_matched is
  * n1 x 2 floats, updated in place (:775-779); bounds = Frame::mnMinX..mnMaxY.  Host pointers, synchronous. */

@@ -46,6 +46,7 @@ SIGNATURES = {
     "orbm_match_groups": (_i, [_vp, _vp, _i, _vp, _i, _i] + [_vp] * 8 + [_i, _i, _f, _i, _vp, _vp]),
     "orbm_match_bruteforce_device": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp, _vp, _vp]),
     "orbm_match_pairs_device": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _f, _i, _vp, _vp, _vp]),
+    "orbm_debug_counters": (_i, [_vp, _i, _vp]),
     "orbm_match_window": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _f, _f, _f, _f, _i, _i, _f, _i, _vp]),
 }
 # debug hooks that run host builds of the shared host/device cores (no GPU needed)

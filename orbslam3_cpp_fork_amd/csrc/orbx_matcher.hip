@@ -26,7 +26,8 @@
 
 namespace {
 
-constexpr int      kTopK       = 4;
+constexpr int      kTopK       = 8;      // merged list depth handed to the resolve pass
+constexpr int      kLaneK      = 4;      // per-lane depth kept while scanning
 constexpr uint32_t kEmpty      = 0xffffffffu;
 constexpr int      kPosBits    = 22;
 constexpr uint32_t kPosMask    = (1u << kPosBits) - 1u;
@@ -54,9 +55,9 @@ __device__ __forceinline__ int hamming256(const uint4& a0, const uint4& a1, cons
          __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
 }
 
-__device__ __forceinline__ void topk_insert(uint32_t (&k)[kTopK], uint32_t key) {
+__device__ __forceinline__ void topk_insert(uint32_t (&k)[kLaneK], uint32_t key) {
 #pragma unroll
-  for (int j = 0; j < kTopK; j++) {
+  for (int j = 0; j < kLaneK; j++) {
     if (key < k[j]) {
       const uint32_t t = k[j];
       k[j]             = key;
@@ -77,15 +78,18 @@ __device__ __forceinline__ int wave_sum_i32(int v) {
 }
 
 // Scan positions [lo, hi) with 64 lanes; cand(pos) returns the train row or -1 (filtered);
-// dist_ok(row, dist) is a second, distance-dependent filter.  All lanes return the K smallest keys.
+// dist_ok(row, dist) is a second, distance-dependent filter.  Every lane keeps its kLaneK smallest keys; the wave
+// then pops the global minimum up to kTopK times.  The popped sequence is the exact sorted prefix of ALL
+// candidates as long as no lane that saw more than kLaneK candidates has run out of kept keys -- the merge stops
+// right there, so `out` is always an exact prefix (unused slots = kEmpty) and *nvalid tells whether it is complete.
 template <class CandFn, class DistFn>
 __device__ __forceinline__ void wave_topk(const uint8_t* __restrict__ qd, const uint8_t* __restrict__ tdesc, int lo, int hi, CandFn cand,
                                           DistFn dist_ok, uint32_t (&out)[kTopK], int* nvalid) {
   const int   lane = threadIdx.x & 63;
   const uint4 a0 = *reinterpret_cast<const uint4*>(qd), a1 = *reinterpret_cast<const uint4*>(qd + 16);
-  uint32_t    k[kTopK];
+  uint32_t    k[kLaneK];
 #pragma unroll
-  for (int j = 0; j < kTopK; j++) k[j] = kEmpty;
+  for (int j = 0; j < kLaneK; j++) k[j] = kEmpty;
   int cnt = 0;
   for (int pos = lo + lane; pos < hi; pos += 64) {
     const int row = cand(pos);
@@ -95,15 +99,20 @@ __device__ __forceinline__ void wave_topk(const uint8_t* __restrict__ qd, const 
     cnt++;
     topk_insert(k, ((uint32_t)d << kPosBits) | (uint32_t)pos);
   }
+  bool stop = false;
 #pragma unroll
   for (int j = 0; j < kTopK; j++) {
-    const uint32_t m = wave_min_u32(k[0]);
-    out[j]           = m;
+    uint32_t m = kEmpty;
+    if (!stop) m = wave_min_u32(k[0]);
+    out[j]        = m;
+    bool exhausted = false;
     if (m != kEmpty && k[0] == m) {  // positions are unique: exactly one lane pops
 #pragma unroll
-      for (int t = 0; t + 1 < kTopK; t++) k[t] = k[t + 1];
-      k[kTopK - 1] = kEmpty;
+      for (int t = 0; t + 1 < kLaneK; t++) k[t] = k[t + 1];
+      k[kLaneK - 1] = kEmpty;
+      exhausted     = k[0] == kEmpty && cnt > kLaneK;  // this lane dropped candidates: what follows is unknown
     }
+    stop = stop || m == kEmpty || __ballot(exhausted) != 0ull;
   }
   *nvalid = wave_sum_i32(cnt);
 }
@@ -161,6 +170,7 @@ struct GroupArgs {
   const int* pairs;
   const int* counts;  // [frames][2]: n, monoIndex
   int        cap;
+  int*       dbg;  // optional tuning counters: [0] speculative rounds, [1] exact rescans, [2] 64-query chunks
 };
 
 // Per-pair view of the batch form.
@@ -231,121 +241,240 @@ __global__ __launch_bounds__(256) void k_group_topk(GroupArgs a0) {
   }
 }
 
-__global__ __launch_bounds__(64) void k_group_resolve(GroupArgs a0) {
+// Ordered claim resolution.  The reference walks the queries one by one and every accepted match removes its
+// train row from all later queries' candidate sets (src/ORBmatcher.cc:290-292, 337).  A query's outcome can
+// therefore only be changed by an EARLIER query that claims a row of its K-list.  The kernel takes 64 queries
+// at a time and runs speculative rounds:
+//   1. every unresolved lane evaluates its own query against the committed claim bitmap;
+//   2. accepting lanes post their lane id on their train row (atomicMin into a small hashed table), so that
+//      every row knows the EARLIEST lane proposing it in this round;
+//   3. a lane is "touched" if an earlier lane proposes a row its decision rests on: its own best row, or -- for a
+//      lane that currently fails the ratio test -- its second-best row (losing that row can only RAISE the
+//      second distance, which never turns an accept into a reject, so accepting lanes ignore it);
+//   4. the untouched prefix (in query order) is committed -- the first unresolved lane always is, its
+//      evaluation being exact -- and the rest re-evaluate in the next round.
+// Hash collisions only add false "touched" flags (an extra round), never a wrong commit.
+// The rare exact rescan (truncated K-list that cannot be decided by the dK bound) is done by the whole wave
+// for the first unresolved lane only.
+constexpr int kResolveThreads = 256;
+constexpr int kSuper          = 512;   // queries staged in LDS per super-chunk
+constexpr int kLaneTab        = 4096;  // proposal table entries (hash = row mod 4096: exact below 4096 train rows)
+
+__global__ __launch_bounds__(kResolveThreads) void k_group_resolve(GroupArgs a0) {
   const GroupArgs     a = pair_view(a0, blockIdx.x);
   __shared__ uint32_t claimed[kMaxTrain / 32];
+  __shared__ uint32_t minLane[kLaneTab];      // earliest proposing lane per (hashed) train row in the current round
+  __shared__ uint32_t sList[kSuper][kTopK];  // dist << 16 | train row  (0xffffffff = empty)
+  __shared__ int      sBestT[kSuper];        // committed train row per staged query (-1 = none)
+  __shared__ uint8_t  sTrunc[kSuper];
   __shared__ int      hist[kHistoLen];
-  const int           lane = threadIdx.x;
-  const int           nq   = a.d_nq ? *a.d_nq : a.nq;
-  const int           nt   = a.d_nt ? *a.d_nt : a.nt;
-  const int           nqe  = a.q_idx ? a.nqe : nq;
-  for (int i = lane; i < (nt + 31) / 32; i += 64) claimed[i] = 0;
-  for (int i = lane; i < kHistoLen; i += 64) hist[i] = 0;
-  for (int i = lane; i < nq; i += 64) a.match_t_of_q[i] = -1;
-  for (int i = lane; i < nt; i += 64) a.match_q_of_t[i] = -1;
+  __shared__ int      sNm;
+  const int           tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int           nq  = a.d_nq ? *a.d_nq : a.nq;
+  const int           nt  = a.d_nt ? *a.d_nt : a.nt;
+  const int           nqe = a.q_idx ? a.nqe : nq;
+  for (int i = tid; i < (nt + 31) / 32; i += kResolveThreads) claimed[i] = 0;
+  for (int i = tid; i < kLaneTab; i += kResolveThreads) minLane[i] = 0xffu;
+  for (int i = tid; i < kHistoLen; i += kResolveThreads) hist[i] = 0;
+  for (int i = tid; i < nq; i += kResolveThreads) a.match_t_of_q[i] = -1;
+  for (int i = tid; i < nt; i += kResolveThreads) a.match_q_of_t[i] = -1;
+  if (tid == 0) sNm = 0;
   __syncthreads();
-  int nmatches = 0;
-  for (int e0 = 0; e0 < nqe; e0 += 64) {
-    // queries whose unconstrained best already fails the threshold can never match: claims only remove candidates
-    const int e   = e0 + lane;
-    bool      pos = false;
-    if (e < nqe) {
-      const uint32_t k0 = a.topk[(size_t)e * kTopK];
-      if (k0 != kEmpty) {
-        const int d = (int)(k0 >> kPosBits);
-        pos         = a.strict_lt ? d < a.th : d <= a.th;
+  for (int s0 = 0; s0 < nqe; s0 += kSuper) {
+    const int ns = min(kSuper, nqe - s0);
+    // ---- stage: all waves fetch the K-lists of this super-chunk (one round of global latency for 1024 queries)
+    for (int i = tid; i < ns; i += kResolveThreads) {
+      const int   e   = s0 + i;
+      const uint4 kk0 = *reinterpret_cast<const uint4*>(a.topk + (size_t)e * kTopK);
+      const uint4 kk1 = *reinterpret_cast<const uint4*>(a.topk + (size_t)e * kTopK + 4);
+      const uint32_t ks[kTopK] = {kk0.x, kk0.y, kk0.z, kk0.w, kk1.x, kk1.y, kk1.z, kk1.w};
+      int            len       = 0;
+#pragma unroll
+      for (int j = 0; j < kTopK; j++) {
+        uint32_t v = kEmpty;
+        if (ks[j] != kEmpty) {
+          const int p   = (int)(ks[j] & kPosMask);
+          const int row = a.t_idx ? a.t_idx[p] : p;
+          v             = ((ks[j] >> kPosBits) << 16) | (uint32_t)row;
+          len           = j + 1;
+        }
+        sList[i][j] = v;
       }
+      sTrunc[i] = a.nvalid[e] > len;  // candidates exist beyond the (exact) list prefix
+      sBestT[i] = -1;
     }
-    unsigned long long mask = __ballot(pos);
-    while (mask) {
-      const int b  = __ffsll((long long)mask) - 1;
-      mask &= mask - 1;
-      const int ee = e0 + b;
-      const int rq = a.q_idx ? a.q_idx[ee] : ee;
-      int       best = 256, second = 256, bestT = -1, found = 0;
-      for (int j = 0; j < kTopK && found < 2; j++) {
-        const uint32_t key = a.topk[(size_t)ee * kTopK + j];
-        if (key == kEmpty) break;
-        const int p   = (int)(key & kPosMask);
-        const int row = a.t_idx ? a.t_idx[p] : p;
-        if (claimed[row >> 5] & (1u << (row & 31))) continue;
-        const int d = (int)(key >> kPosBits);
-        if (found == 0) {
-          best = d, bestT = row;
-        } else {
-          second = d;
+    __syncthreads();
+    // ---- resolve: wave 0 walks the staged queries 64 at a time in speculative rounds (see above), LDS only
+    if (wave == 0) {
+      int nmatches = 0;
+      for (int c0 = 0; c0 < ns; c0 += 64) {
+        const int i = c0 + lane;
+        uint32_t  ks[kTopK];
+#pragma unroll
+        for (int j = 0; j < kTopK; j++) ks[j] = i < ns ? sList[i][j] : kEmpty;
+        const bool truncated = i < ns ? sTrunc[i] != 0 : false;
+        bool       pos       = false;
+        if (ks[0] != kEmpty) {
+          const int d = (int)(ks[0] >> 16);
+          pos         = a.strict_lt ? d < a.th : d <= a.th;
         }
-        found++;
-      }
-      if (found < 2 && a.nvalid[ee] > kTopK) {
-        // the K-list was truncated and ran dry: exact rescan of the group with the claim filter
-        int lo = 0, hi = nt;
-        if (a.q_idx) {
-          const int g = group_of(a, ee);
-          lo = a.t_off[g], hi = a.t_off[g + 1];
-        }
-        const int*      t_idx   = a.t_idx;
-        const uint8_t*  t_valid = a.t_valid;
-        const uint32_t* cl      = claimed;
-        uint32_t        out[kTopK];
-        int             nv;
-        wave_topk(
-            a.q + (size_t)rq * 32, a.t, lo, hi,
-            [t_idx, t_valid, cl](int p) {
-              const int row = t_idx ? t_idx[p] : p;
-              if (t_valid && !t_valid[row]) return -1;
-              return (cl[row >> 5] & (1u << (row & 31))) ? -1 : row;
-            },
-            [](int, int) { return true; }, out, &nv);
-        best = 256, second = 256, bestT = -1;
-        if (out[0] != kEmpty) {
-          const int p = (int)(out[0] & kPosMask);
-          best        = (int)(out[0] >> kPosBits);
-          bestT       = a.t_idx ? a.t_idx[p] : p;
-        }
-        if (out[1] != kEmpty) second = (int)(out[1] >> kPosBits);
-      }
-      const bool pass = a.strict_lt ? best < a.th : best <= a.th;
-      if (pass && (float)best < a.ratio * (float)second) {
-        if (lane == 0) {
-          claimed[bestT >> 5] |= 1u << (bestT & 31);
-          a.match_t_of_q[rq]    = bestT;
-          a.match_q_of_t[bestT] = rq;
-          if (a.check_ori) {
-            const int bin = rot_bin(a.q_angle[(size_t)rq * a.q_astride], a.t_angle[(size_t)bestT * a.t_astride]);
-            hist[bin]++;
-            a.binOf[rq] = bin;
+        int dK = 0;  // distance of the last list entry: lower bound for every candidate outside the list
+#pragma unroll
+        for (int j = 0; j < kTopK; j++)
+          if (ks[j] != kEmpty) dK = (int)(ks[j] >> 16);
+        int                myBestT   = -1;
+        unsigned long long remaining = __ballot(pos);
+        if (a.dbg && lane == 0) atomicAdd(&a.dbg[2], 1);
+        while (remaining) {
+          if (a.dbg && lane == 0) atomicAdd(&a.dbg[0], 1);
+          const bool active = (remaining >> lane) & 1ull;
+          int        best = 256, second = 256, bestT = -1, secondT = -1, found = 0;
+          bool       rescan = false, accept = false, passBest = false;
+          if (active) {
+            bool free_[kTopK];  // independent LDS reads first, the ordered pick afterwards
+#pragma unroll
+            for (int j = 0; j < kTopK; j++) {
+              const int row = (int)(ks[j] & 0xffffu);
+              free_[j]      = ks[j] != kEmpty && !(claimed[row >> 5] & (1u << (row & 31)));
+            }
+#pragma unroll
+            for (int j = 0; j < kTopK; j++) {
+              if (found < 2 && free_[j]) {
+                const int row = (int)(ks[j] & 0xffffu);
+                const int d   = (int)(ks[j] >> 16);
+                if (found == 0)
+                  best = d, bestT = row;
+                else
+                  second = d, secondT = row;
+                found++;
+              }
+            }
+            // a truncated K-list that ran dry still bounds what lies beyond it: every other candidate is >= dK away
+            passBest = a.strict_lt ? best < a.th : best <= a.th;
+            if (found < 2 && truncated) {
+              if (found == 1) {
+                if (passBest && !((float)best < a.ratio * (float)dK)) rescan = true;
+                if (passBest && !rescan) second = dK;  // any value >= dK gives the same decision
+              } else {
+                rescan = a.strict_lt ? dK < a.th : dK <= a.th;
+              }
+            }
+            if (!rescan) accept = passBest && (float)best < a.ratio * (float)second;
           }
+          const int first = __ffsll((long long)remaining) - 1;
+          if (__shfl((int)rescan, first, 64)) {
+            // exact rescan of the first unresolved query's group with the claim filter (whole wave)
+            if (a.dbg && lane == 0) atomicAdd(&a.dbg[1], 1);
+            const int ee = s0 + c0 + first;
+            const int rq = a.q_idx ? a.q_idx[ee] : ee;
+            int       lo = 0, hi = nt;
+            if (a.q_idx) {
+              const int g = group_of(a, ee);
+              lo = a.t_off[g], hi = a.t_off[g + 1];
+            }
+            const int*      t_idx   = a.t_idx;
+            const uint8_t*  t_valid = a.t_valid;
+            const uint32_t* cl      = claimed;
+            uint32_t        out[kTopK];
+            int             nv;
+            wave_topk(
+                a.q + (size_t)rq * 32, a.t, lo, hi,
+                [t_idx, t_valid, cl](int p) {
+                  const int row = t_idx ? t_idx[p] : p;
+                  if (t_valid && !t_valid[row]) return -1;
+                  return (cl[row >> 5] & (1u << (row & 31))) ? -1 : row;
+                },
+                [](int, int) { return true; }, out, &nv);
+            int b1 = 256, b2 = 256, bT = -1;
+            if (out[0] != kEmpty) {
+              const int p = (int)(out[0] & kPosMask);
+              b1          = (int)(out[0] >> kPosBits);
+              bT          = a.t_idx ? a.t_idx[p] : p;
+            }
+            if (out[1] != kEmpty) b2 = (int)(out[1] >> kPosBits);
+            const bool pass = a.strict_lt ? b1 < a.th : b1 <= a.th;
+            if (pass && (float)b1 < a.ratio * (float)b2) {
+              if (lane == first) {
+                claimed[bT >> 5] |= 1u << (bT & 31);
+                myBestT = bT;
+              }
+              nmatches++;
+            }
+            remaining &= ~(1ull << first);
+            continue;
+          }
+          // tentative proposals: earliest proposing lane per row
+          if (active && accept) atomicMin(&minLane[bestT & (kLaneTab - 1)], (uint32_t)lane);
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          bool touched = false;
+          if (active) {
+            if (rescan) {
+              touched = true;
+            } else if (passBest && found > 0) {
+              touched = minLane[bestT & (kLaneTab - 1)] < (uint32_t)lane;
+              if (!accept && secondT >= 0) touched = touched || minLane[secondT & (kLaneTab - 1)] < (uint32_t)lane;
+            }
+          }
+          const unsigned long long tmask = __ballot(touched) & ~(1ull << first);
+          const int                limit = tmask ? __ffsll((long long)tmask) - 1 : 64;
+          const unsigned long long fin   = limit >= 64 ? remaining : (remaining & ((1ull << limit) - 1ull));
+          const bool               mine  = (fin >> lane) & 1ull;
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          if (active && accept) minLane[bestT & (kLaneTab - 1)] = 0xffu;  // retract (all reads above are done: same wave, in order)
+          if (mine && accept) {
+            atomicOr(&claimed[bestT >> 5], 1u << (bestT & 31));
+            myBestT = bestT;
+          }
+          nmatches += __popcll(__ballot(mine && accept));
+          remaining &= ~fin;
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
-        nmatches++;
-        __syncthreads();  // single-wave workgroup: orders lane 0's LDS/global writes before the next reads
+        if (i < ns) sBestT[i] = myBestT;
+      }
+      if (lane == 0) sNm += nmatches;
+    }
+    __syncthreads();
+    // ---- publish: all waves write the committed matches of the super-chunk and vote in the rotation histogram
+    for (int i = tid; i < ns; i += kResolveThreads) {
+      const int bT = sBestT[i];
+      if (bT >= 0) {
+        const int e  = s0 + i;
+        const int rq = a.q_idx ? a.q_idx[e] : e;
+        a.match_t_of_q[rq] = bT;
+        a.match_q_of_t[bT] = rq;
+        if (a.check_ori) {
+          const int bin = rot_bin(a.q_angle[(size_t)rq * a.q_astride], a.t_angle[(size_t)bT * a.t_astride]);
+          atomicAdd(&hist[bin], 1);
+          a.binOf[rq] = bin;
+        }
       }
     }
+    __syncthreads();
   }
-  __syncthreads();
   if (a.check_ori) {
+    __shared__ int sRemoved;
+    if (tid == 0) sRemoved = 0;
+    __syncthreads();
     int i1, i2, i3;
     three_maxima(hist, kHistoLen, i1, i2, i3);
     int removed = 0;
-    for (int q0 = 0; q0 < nq; q0 += 64) {
-      const int q    = q0 + lane;
-      bool      drop = false;
-      if (q < nq) {
-        const int m = a.match_t_of_q[q];
-        if (m >= 0) {
-          const int bin = a.binOf[q];
-          if (bin != i1 && bin != i2 && bin != i3) {
-            drop                = true;
-            a.match_q_of_t[m]   = -1;
-            a.match_t_of_q[q]   = -1;
-          }
+    for (int q = tid; q < nq; q += kResolveThreads) {
+      const int m = a.match_t_of_q[q];
+      if (m >= 0) {
+        const int bin = a.binOf[q];
+        if (bin != i1 && bin != i2 && bin != i3) {
+          removed++;
+          a.match_q_of_t[m] = -1;
+          a.match_t_of_q[q] = -1;
         }
       }
-      removed += __popcll(__ballot(drop));
     }
-    nmatches -= removed;
+    if (removed) atomicAdd(&sRemoved, removed);
+    __syncthreads();
+    if (tid == 0) sNm -= sRemoved;
   }
-  if (lane == 0) *a.nmatches = nmatches;
+  __syncthreads();
+  if (tid == 0) *a.nmatches = sNm;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -451,7 +580,23 @@ __global__ __launch_bounds__(64) void k_window_resolve(WindowArgs a) {
         }
         found++;
       }
-      if (found < 2 && a.nvalid[i1] > kTopK) {
+      bool rescan = false;
+      int listLen = 0, dK = 0;
+      for (int j = 0; j < kTopK; j++) {
+        const uint32_t key = a.topk[(size_t)i1 * kTopK + j];
+        if (key == kEmpty) break;
+        listLen = j + 1;
+        dK      = (int)(key >> kPosBits);
+      }
+      if (found < 2 && a.nvalid[i1] > listLen) {  // same dK bound as in k_group_resolve
+        if (found == 1) {
+          if (best <= a.th && !((float)best < (float)dK * a.ratio)) rescan = true;
+          if (best <= a.th && !rescan) second = dK;
+        } else {
+          rescan = dK <= a.th;
+        }
+      }
+      if (rescan) {
         const float               x = a.prev[2 * i1], y = a.prev[2 * i1 + 1];
         const WinRange            w  = window_cells(a, x, y);
         const WindowArgs&         ar = a;
@@ -547,7 +692,8 @@ struct orbm_matcher {
   int         device = 0;
   hipStream_t stream = nullptr;
   DBuf<uint8_t>         dq, dt, dqv, dtv, gcx, gcy;
-  DBuf<int>             qoff, qidx, toff, tidx, nvalid, binOf, mq, mt, nm, gidx;
+  DBuf<int>             qoff, qidx, toff, tidx, nvalid, binOf, mq, mt, nm, gidx, dbg;
+  bool                  dbgOn = false;
   DBuf<float>           qa, ta, prev;
   DBuf<uint32_t>        topk;
   DBuf<orbx_keypoint_t> kp1, kp2;
@@ -581,8 +727,25 @@ void orbm_destroy(orbm_t* h) {
   h->dq.release(), h->dt.release(), h->dqv.release(), h->dtv.release(), h->gcx.release(), h->gcy.release(), h->qoff.release();
   h->qidx.release(), h->toff.release(), h->tidx.release(), h->nvalid.release(), h->binOf.release(), h->mq.release(), h->mt.release();
   h->nm.release(), h->gidx.release(), h->qa.release(), h->ta.release(), h->prev.release(), h->topk.release(), h->kp1.release();
-  h->kp2.release();
+  h->kp2.release(), h->dbg.release();
   delete h;
+}
+
+// Tuning hook: enable == 1 zeroes and arms the counters {speculative rounds, exact rescans, 64-query chunks} of
+// orbm_match_pairs_device; enable == 0 synchronises and reads them into out[3].
+int orbm_debug_counters(orbm_t* h, int enable, int* out) {
+  if (!h) return -2;
+  HIP_TRYM(hipSetDevice(h->device));
+  if (enable) {
+    if (h->dbg.ensure(4)) return -3;
+    HIP_TRYM(hipMemset(h->dbg.p, 0, 16));
+    h->dbgOn = true;
+    return 0;
+  }
+  HIP_TRYM(hipDeviceSynchronize());
+  if (out && h->dbg.p) HIP_TRYM(hipMemcpy(out, h->dbg.p, 12, hipMemcpyDeviceToHost));
+  h->dbgOn = false;
+  return 0;
 }
 
 int orbm_hamming(const uint8_t* a, const uint8_t* b) {
@@ -621,7 +784,7 @@ void orbm_three_maxima(const int* counts, int len, int* ind1, int* ind2, int* in
 static int launch_groups(orbm_matcher* h, GroupArgs& a, int nq_cap, hipStream_t s, int npairs = 1) {
   const int nqe = a.q_idx ? a.nqe : nq_cap;
   if (nqe > 0) hipLaunchKernelGGL(k_group_topk, dim3((nqe + 3) / 4, npairs), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(k_group_resolve, dim3(npairs), dim3(64), 0, s, a);
+  hipLaunchKernelGGL(k_group_resolve, dim3(npairs), dim3(kResolveThreads), 0, s, a);
   HIP_TRYM(hipGetLastError());
   return 0;
 }
@@ -760,6 +923,7 @@ int orbm_match_pairs_device(orbm_t* h, const uint8_t* d_desc, const orbx_keypoin
   a.topk = h->topk.p, a.nvalid = h->nvalid.p, a.binOf = h->binOf.p;
   a.match_t_of_q = d_match_t_of_q, a.match_q_of_t = h->mt.p, a.nmatches = d_nmatches;
   a.pairs = d_pairs, a.counts = d_counts, a.cap = cap;
+  if (h->dbgOn && !h->dbg.ensure(4)) a.dbg = h->dbg.p;
   return launch_groups(h, a, cap, stream ? (hipStream_t)stream : h->stream, npairs);
 }
 

@@ -125,8 +125,9 @@ def test_batch_device_matches_single(oracle, gpu_ex):
     d_kps = torch.zeros((B, cap, 7), dtype=torch.float32, device="cuda")
     d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
     d_cnt = torch.zeros((B, 2), dtype=torch.int32, device="cuda")
-    s = torch.cuda.current_stream().cuda_stream
-    gpu_ex.extract_batch_device(d_imgs, B, h, w, w, h * w, d_kps, d_desc, d_cnt, cap, (0, 1000), stream=s)
+    ts = torch.cuda.Stream()
+    with torch.cuda.stream(ts):
+        gpu_ex.extract_batch_device(d_imgs, B, h, w, w, h * w, d_kps, d_desc, d_cnt, cap, (0, 1000), stream=ts.cuda_stream)
     torch.cuda.synchronize()
     cnt = d_cnt.cpu().numpy()
     oex = oracle.OracleExtractor(1000, 1.2, 8, 20, 7)
