@@ -184,10 +184,10 @@ int orbx_extractor::makeGeometry(int rows, int cols) {
     L.scale     = sf[l];
     L.patchSize = (int)(kPatchSize * sf[l]);  // src/ORBextractor.cc:865
     // blur tiles
-    L.blurTilesX   = (L.w + kBlurTileW - 1) / kBlurTileW;
-    L.blurTilesY   = (L.h + kBlurTileH - 1) / kBlurTileH;
-    L.blurTileBase = tileBase;
-    tileBase += L.blurTilesX * L.blurTilesY;
+    L.blurTilesX   = (L.w + 3) / 4;                          // 4-column groups
+    L.blurTilesY   = (L.h + kBlurRows - 1) / kBlurRows;      // row strips
+    L.blurTileBase = tileBase;                               // in workgroups of 256 items
+    tileBase += (L.blurTilesX * L.blurTilesY + 255) / 256;
     // cv::resize INTER_LINEAR tables (OpenCV resize.cpp)
     L.xtabOff = (int)xt.size();
     L.ytabOff = (int)yt.size();

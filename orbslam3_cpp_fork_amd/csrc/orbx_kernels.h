@@ -107,6 +107,9 @@ __global__ __launch_bounds__(256) void k_resize_level(Bufs b, FrameGeom g, int l
 // s_t, with neighbours outside the cell's 3-px-inset interior counting as 0 (they are never scored
 // by cv::FAST on the sub-image).  Output order is row-major, as cv::FAST emits.
 // ------------------------------------------------------------------------------------------------
+// idx / d for 0 <= idx < 65536, 1 <= d <= 256 with one multiply-high: m = floor(2^32 / d) + 1.
+__device__ __forceinline__ int div_magic(unsigned idx, unsigned m) { return m ? (int)__umulhi(idx, m) : (int)idx; }  // m == 0 encodes d == 1
+
 __device__ __forceinline__ int fast_score(const uint8_t (*tile)[kFastTileMax], int x, int y) {
   const int v = tile[y][x];
   int       d[16];
@@ -149,10 +152,11 @@ __device__ __forceinline__ int fast_score(const uint8_t (*tile)[kFastTileMax], i
 }
 
 __global__ __launch_bounds__(256) void k_fast_cells(Bufs b, FrameGeom g, int iniTh, int minTh) {
-  __shared__ uint8_t tile[kFastTileMax][kFastTileMax];
-  __shared__ uint8_t score[kFastTileMax][kFastTileMax];
+  __shared__ __align__(16) uint8_t tile[kFastTileMax][kFastTileMax];
+  __shared__ __align__(16) uint8_t score[kFastTileMax][kFastTileMax];
   __shared__ int     wavePre[2][24][4];  // per (threshold, iteration, wave) keypoint counts -> exclusive offsets
-  __shared__ int     selTh, selTot;
+  __shared__ int     selTh, selTot, candCount;
+  __shared__ unsigned short candList[(kFastTileMax - 6) * (kFastTileMax - 6)];
   const int          cell = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
   int                level = 0;
   while (level + 1 < g.nlevels && cell >= g.lv[level + 1].cellBase) level++;
@@ -174,16 +178,59 @@ __global__ __launch_bounds__(256) void k_fast_cells(Bufs b, FrameGeom g, int ini
   }
   int            pitch;
   const uint8_t* img = level_raw(b, g, level, f, &pitch) + (long long)iniY * pitch + iniX;
-  for (int idx = tid; idx < tw * th; idx += 256) {
-    const int y = idx / tw, x = idx - y * tw;
-    tile[y][x]  = img[(long long)y * pitch + x];
-    score[y][x] = 0;
+  const unsigned mIw = 0xffffffffu / (unsigned)iw + 1u;  // interior-width divider for idx -> (row, col)
+  {
+    // tile load: 4 pixels per thread where the row is 4-byte aligned in memory, bytes otherwise
+    const int      tw4  = (tw + 3) >> 2;
+    const unsigned mT4  = 0xffffffffu / (unsigned)tw4 + 1u;
+    const bool     al4  = ((pitch & 3) == 0) && ((reinterpret_cast<uintptr_t>(img) & 3) == 0);
+    for (int idx = tid; idx < tw4 * th; idx += 256) {
+      const int y = div_magic(idx, mT4), x = (idx - y * tw4) * 4;
+      const uint8_t* src = img + (long long)y * pitch + x;
+      uint32_t       v;
+      if (al4 && x + 4 <= tw) {
+        v = *reinterpret_cast<const uint32_t*>(src);
+      } else {
+        v = src[0];
+        if (x + 1 < tw) v |= (uint32_t)src[1] << 8;
+        if (x + 2 < tw) v |= (uint32_t)src[2] << 16;
+        if (x + 3 < tw) v |= (uint32_t)src[3] << 24;
+      }
+      *reinterpret_cast<uint32_t*>(&tile[y][x])  = v;  // kFastTileMax is a multiple of 4: aligned; spill past tw stays inside the row
+      *reinterpret_cast<uint32_t*>(&score[y][x]) = 0;
+    }
   }
   __syncthreads();
   const int npix  = iw * ih;
   const int lowTh = max(min(iniTh, minTh), 1);
-  for (int idx = tid; idx < npix; idx += 256) {
-    const int y = 3 + idx / iw, x = 3 + idx % iw;
+  // Pass 1 -- cheap necessary condition + compaction.  A 9-arc of the 16-pixel circle always contains two
+  // ADJACENT compass points (0, 4, 8, 12), so a pixel can only score >= lowTh if two adjacent compass pixels are
+  // both darker than v - lowTh or both brighter than v + lowTh.  Survivors are appended (any order) to an LDS
+  // list so that pass 2 evaluates the full score with all lanes busy.
+  if (tid == 0) candCount = 0;
+  __syncthreads();
+  for (int idx = tid; idx < ((npix + 63) & ~63); idx += 256) {
+    bool keep = false;
+    if (idx < npix) {
+      const int q = div_magic(idx, mIw), y = 3 + q, x = 3 + idx - q * iw;
+      const int v = tile[y][x];
+      const int d0 = v - tile[y + 3][x], d4 = v - tile[y][x + 3], d8 = v - tile[y - 3][x], d12 = v - tile[y][x - 3];
+      const bool k0 = d0 > lowTh, k4 = d4 > lowTh, k8 = d8 > lowTh, k12 = d12 > lowTh;
+      const bool b0 = -d0 > lowTh, b4 = -d4 > lowTh, b8 = -d8 > lowTh, b12 = -d12 > lowTh;
+      keep = (k0 && k4) || (k4 && k8) || (k8 && k12) || (k12 && k0) || (b0 && b4) || (b4 && b8) || (b8 && b12) || (b12 && b0);
+    }
+    const unsigned long long bal = __ballot(keep);
+    int                      base = 0;
+    if ((tid & 63) == 0 && bal) base = atomicAdd(&candCount, __popcll(bal));
+    base = __shfl(base, 0, 64);
+    if (keep) candList[base + __popcll(bal & ((1ull << (tid & 63)) - 1ull))] = (unsigned short)idx;
+  }
+  __syncthreads();
+  // Pass 2 -- full corner score of the survivors
+  const int ncand = candCount;
+  for (int k = tid; k < ncand; k += 256) {
+    const int idx = candList[k];
+    const int q = div_magic(idx, mIw), y = 3 + q, x = 3 + idx - q * iw;
     const int s = fast_score(tile, x, y);
     score[y][x] = (uint8_t)(s >= lowTh ? s : 0);  // scores below both thresholds are never corners
   }
@@ -196,7 +243,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(Bufs b, FrameGeom g, int ini
     const int idx = it * 256 + tid;
     bool      f1 = false, f2 = false;
     if (idx < npix) {
-      const int y = 3 + idx / iw, x = 3 + idx % iw;
+      const int q = div_magic(idx, mIw), y = 3 + q, x = 3 + idx - q * iw;
       const int s = score[y][x];
       if (s > 0) {
         int m1 = 0, m2 = 0;  // max neighbour score under each threshold
@@ -246,7 +293,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(Bufs b, FrameGeom g, int ini
     bool      flag = false;
     int       x = 0, y = 0, s = 0;
     if (idx < npix) {
-      y = 3 + idx / iw, x = 3 + idx % iw;
+      { const int q = div_magic(idx, mIw); y = 3 + q, x = 3 + idx - q * iw; }
       s = score[y][x];
       if (s >= thr) {
         int m = 0;
@@ -401,44 +448,68 @@ __device__ __forceinline__ int reflect101(int p, int n) {
   return p;
 }
 
+// Register sliding-window form: a thread owns 4 adjacent columns of a kBlurRows-row strip.  It streams the
+// strip's kBlurRows + 6 input rows once (three aligned 32-bit loads per row: columns x0-4 .. x0+7), forms the
+// horizontal Q8 sums of its 4 columns, keeps the last 7 of them in registers and emits one output row
+// (4 bytes, one store) per input row.  No LDS, no second pass; neighbouring lanes' overlapping loads hit L1.
+// Work items are dealt level by level, 256 per workgroup (LevelGeom::blurTileBase counts workgroups).
+constexpr int kBlurRows = 16;
+
+__device__ __forceinline__ void blur_load10(const uint8_t* __restrict__ row, int x0, int w, bool fast, int (&p)[10]) {
+  if (fast) {
+    const uint32_t a = *reinterpret_cast<const uint32_t*>(row + x0 - 4);
+    const uint32_t m = *reinterpret_cast<const uint32_t*>(row + x0);
+    const uint32_t c = *reinterpret_cast<const uint32_t*>(row + x0 + 4);
+    p[0] = (a >> 8) & 0xff, p[1] = (a >> 16) & 0xff, p[2] = a >> 24;
+    p[3] = m & 0xff, p[4] = (m >> 8) & 0xff, p[5] = (m >> 16) & 0xff, p[6] = m >> 24;
+    p[7] = c & 0xff, p[8] = (c >> 8) & 0xff, p[9] = (c >> 16) & 0xff;
+  } else {
+#pragma unroll
+    for (int i = 0; i < 10; i++) p[i] = row[reflect101(x0 - 3 + i, w)];
+  }
+}
+
 __global__ __launch_bounds__(256) void k_blur_levels(Bufs b, FrameGeom g) {
-  __shared__ uint8_t  in[kBlurTileH + 6][kBlurTileW + 8];
-  __shared__ uint16_t hb[kBlurTileH + 6][kBlurTileW];
-  const int           f = blockIdx.y, tid = threadIdx.x;
-  int                 t = blockIdx.x, level = 0;
+  const int f = blockIdx.y, tid = threadIdx.x;
+  int       t = blockIdx.x, level = 0;
   while (level + 1 < g.nlevels && t >= g.lv[level + 1].blurTileBase) level++;
-  const LevelGeom& L = g.lv[level];
-  t -= L.blurTileBase;
-  const int      ty = t / L.blurTilesX, tx = t - ty * L.blurTilesX;
-  const int      x0 = tx * kBlurTileW, y0 = ty * kBlurTileH;
+  const LevelGeom& L      = g.lv[level];
+  const int        groups = (L.w + 3) >> 2;
+  const int        item   = (t - L.blurTileBase) * 256 + tid;
+  const int        strip  = item / groups;
+  const int        x0     = (item - strip * groups) * 4;
+  const int        y0     = strip * kBlurRows;
+  if (y0 >= L.h) return;
   int            pitch;
   const uint8_t* src = level_raw(b, g, level, f, &pitch);
-  for (int idx = tid; idx < (kBlurTileH + 6) * (kBlurTileW + 6); idx += 256) {
-    const int yy = idx / (kBlurTileW + 6), xx = idx - yy * (kBlurTileW + 6);
-    const int sy = reflect101(min(y0 + yy - 3, L.h + 2), L.h), sx = reflect101(min(x0 + xx - 3, L.w + 2), L.w);
-    in[yy][xx]   = src[(long long)sy * pitch + sx];
-  }
-  __syncthreads();
-  for (int idx = tid; idx < (kBlurTileH + 6) * kBlurTileW; idx += 256) {
-    const int yy = idx / kBlurTileW, xx = idx - yy * kBlurTileW;
-    const int s  = 18 * (in[yy][xx] + in[yy][xx + 6]) + 34 * (in[yy][xx + 1] + in[yy][xx + 5]) + 48 * (in[yy][xx + 2] + in[yy][xx + 4]) +
-                  56 * in[yy][xx + 3];
-    hb[yy][xx] = (uint16_t)s;
-  }
-  __syncthreads();
-  uint8_t* dst = b.blur + (long long)f * g.blurBytes + L.blurOff;
-  // thread = 4 adjacent outputs of one row
-  const int oy = tid >> 4, ox = (tid & 15) * 4;
-  if (y0 + oy < L.h && x0 + ox < L.w) {
-    uint32_t out = 0;
+  uint8_t*       dst = b.blur + (long long)f * g.blurBytes + L.blurOff;
+  // aligned 32-bit loads need a 4-byte aligned row base; columns x0-4 .. x0+7 must lie inside the row
+  const bool fast = x0 >= 4 && x0 + 8 <= L.w && ((pitch & 3) == 0) && ((reinterpret_cast<uintptr_t>(src) & 3) == 0);
+  int        hr[7][4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const int      xx = ox + k;
-      const uint32_t s  = 18u * (hb[oy][xx] + hb[oy + 6][xx]) + 34u * (hb[oy + 1][xx] + hb[oy + 5][xx]) +
-                         48u * (hb[oy + 2][xx] + hb[oy + 4][xx]) + 56u * hb[oy + 3][xx];
-      out |= ((s + 32768u) >> 16) << (8 * k);
+  for (int r = 0; r < kBlurRows + 6; r++) {
+    const int sy = reflect101(min(y0 + r - 3, L.h + 2), L.h);
+    int       p[10];
+    blur_load10(src + (long long)sy * pitch, x0, L.w, fast, p);
+#pragma unroll
+    for (int k = 0; k < 6; k++)
+#pragma unroll
+      for (int i = 0; i < 4; i++) hr[k][i] = hr[k + 1][i];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+      hr[6][i] = 18 * (p[i] + p[i + 6]) + 34 * (p[i + 1] + p[i + 5]) + 48 * (p[i + 2] + p[i + 4]) + 56 * p[i + 3];
+    if (r >= 6) {
+      const int oy = y0 + r - 6;
+      if (oy < L.h) {
+        uint32_t out = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const uint32_t sacc = 18u * (hr[0][i] + hr[6][i]) + 34u * (hr[1][i] + hr[5][i]) + 48u * (hr[2][i] + hr[4][i]) + 56u * hr[3][i];
+          out |= ((sacc + 32768u) >> 16) << (8 * i);
+        }
+        *reinterpret_cast<uint32_t*>(dst + (long long)oy * L.blurPitch + x0) = out;
+      }
     }
-    *reinterpret_cast<uint32_t*>(dst + (long long)(y0 + oy) * L.blurPitch + x0 + ox) = out;
   }
 }
 
