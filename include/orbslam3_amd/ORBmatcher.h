@@ -1,0 +1,102 @@
+// ORBmatcher.h -- C++ adaptor for the matcher inner loops (reference include/ORBmatcher.h:35-148) over orbm_*.
+// The reference's Search* methods take Frame / KeyFrame objects; the array-level cores they all share are
+// exposed here with the reference's constants and semantics.  INTEGRATION.md shows how
+// ORBmatcher::SearchByBoW(KeyFrame*, Frame&, ...) forwards to SearchByBoWArrays().
+#ifndef ORBSLAM3_AMD_ORBMATCHER_H_
+#define ORBSLAM3_AMD_ORBMATCHER_H_
+
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../orbx.h"
+#include "cv_compat.h"
+
+namespace ORB_SLAM3 {
+
+class ORBmatcher {
+ public:
+  static constexpr int TH_LOW       = 50;   // src/ORBmatcher.cc:31
+  static constexpr int TH_HIGH      = 100;  // src/ORBmatcher.cc:30
+  static constexpr int HISTO_LENGTH = 30;   // src/ORBmatcher.cc:32
+
+  ORBmatcher(float nnratio = 0.6, bool checkOri = true, int device_id = 0) : mfNNratio(nnratio), mbCheckOrientation(checkOri) {
+    if (orbm_create(&h_, device_id) != 0) throw std::runtime_error(std::string("orbm_create: ") + orbx_last_error());
+  }
+  ~ORBmatcher() { orbm_destroy(h_); }
+  ORBmatcher(const ORBmatcher&)            = delete;
+  ORBmatcher& operator=(const ORBmatcher&) = delete;
+
+  // Computes the Hamming distance between two ORB descriptors (reference :40)
+  static int DescriptorDistance(const orbx_cv::Mat& a, const orbx_cv::Mat& b) { return orbm_hamming(a.ptr(0), b.ptr(0)); }
+
+  // DBoW2::FeatureVector is std::map<NodeId, std::vector<unsigned int>>
+  typedef std::map<unsigned int, std::vector<unsigned int>> FeatureVector;
+
+  // Core of SearchByBoW(KeyFrame* pKF, Frame& F, vpMapPointMatches) (src/ORBmatcher.cc:237-421, F.Nleft == -1):
+  // kfHasMapPoint[i] = (vpMapPointsKF[i] && !isBad()); matchKFofF[j] = KeyFrame feature whose MapPoint frame
+  // feature j receives, -1 = NULL.  strictLess selects the KeyFrame-KeyFrame overload's `< TH_LOW` (:864).
+  int SearchByBoWArrays(const orbx_cv::Mat& descKF, const std::vector<float>& angleKF, const FeatureVector& fvKF,
+                        const std::vector<unsigned char>& kfHasMapPoint, const orbx_cv::Mat& descF, const std::vector<float>& angleF,
+                        const FeatureVector& fvF, std::vector<int>& matchKFofF, const std::vector<unsigned char>* fHasMapPoint = nullptr,
+                        bool strictLess = false, std::vector<int>* matchFofKF = nullptr) {
+    std::vector<int> qoff(1, 0), qidx, toff(1, 0), tidx;
+    FeatureVector::const_iterator a = fvKF.begin(), b = fvF.begin();
+    while (a != fvKF.end() && b != fvF.end()) {  // merge walk of :259-399
+      if (a->first == b->first) {
+        qidx.insert(qidx.end(), a->second.begin(), a->second.end());
+        tidx.insert(tidx.end(), b->second.begin(), b->second.end());
+        qoff.push_back((int)qidx.size()), toff.push_back((int)tidx.size());
+        ++a, ++b;
+      } else if (a->first < b->first) {
+        a = fvKF.lower_bound(b->first);
+      } else {
+        b = fvF.lower_bound(a->first);
+      }
+    }
+    matchKFofF.assign(descF.rows, -1);
+    if (matchFofKF) matchFofKF->assign(descKF.rows, -1);
+    const int ng = (int)qoff.size() - 1;
+    if (ng == 0) return 0;
+    std::vector<uint8_t> q = pack(descKF), t = pack(descF);
+    int n = orbm_match_groups(h_, q.data(), descKF.rows, t.data(), descF.rows, ng, qoff.data(), qidx.data(), toff.data(), tidx.data(),
+                              kfHasMapPoint.empty() ? nullptr : kfHasMapPoint.data(), fHasMapPoint ? fHasMapPoint->data() : nullptr,
+                              angleKF.data(), angleF.data(), TH_LOW, strictLess ? 1 : 0, mfNNratio, mbCheckOrientation ? 1 : 0,
+                              matchFofKF ? matchFofKF->data() : nullptr, matchKFofF.data());
+    if (n <= -2) throw std::runtime_error(std::string("orbm_match_groups: ") + orbx_last_error());
+    return n;
+  }
+
+  // SearchForInitialization (src/ORBmatcher.cc:666-782); bounds = Frame::mnMinX, mnMaxX, mnMinY, mnMaxY.
+  int SearchForInitializationArrays(const std::vector<orbx_cv::KeyPoint>& keysUn1, const orbx_cv::Mat& desc1,
+                                    const std::vector<orbx_cv::KeyPoint>& keysUn2, const orbx_cv::Mat& desc2,
+                                    std::vector<orbx_cv::Point2f>& vbPrevMatched, std::vector<int>& vnMatches12, const float bounds[4],
+                                    int windowSize = 10) {
+    vnMatches12.assign(keysUn1.size(), -1);
+    std::vector<uint8_t> d1 = pack(desc1), d2 = pack(desc2);
+    int n = orbm_match_window(h_, d1.data(), reinterpret_cast<const orbx_keypoint_t*>(keysUn1.data()), (int)keysUn1.size(), d2.data(),
+                              reinterpret_cast<const orbx_keypoint_t*>(keysUn2.data()), (int)keysUn2.size(),
+                              reinterpret_cast<float*>(vbPrevMatched.data()), bounds[0], bounds[1], bounds[2], bounds[3], windowSize, TH_LOW,
+                              mfNNratio, mbCheckOrientation ? 1 : 0, vnMatches12.data());
+    if (n <= -2) throw std::runtime_error(std::string("orbm_match_window: ") + orbx_last_error());
+    return n;
+  }
+
+  orbm_t* handle() { return h_; }
+
+ protected:
+  float mfNNratio;
+  bool  mbCheckOrientation;
+
+ private:
+  static std::vector<uint8_t> pack(const orbx_cv::Mat& m) {  // rows may be strided: make them contiguous
+    std::vector<uint8_t> v((size_t)m.rows * 32 + 32);
+    for (int r = 0; r < m.rows; r++) std::memcpy(v.data() + (size_t)r * 32, m.ptr(r), 32);
+    return v;
+  }
+  orbm_t* h_ = nullptr;
+};
+
+}  // namespace ORB_SLAM3
+#endif

@@ -1,0 +1,56 @@
+// Drives the C++ adaptors exactly as Frame::ExtractORB (reference src/Frame.cc:555-562) and
+// Tracking::TrackReferenceKeyFrame (src/Tracking.cc:2603-2606) drive the reference classes, on a raw PGM-less
+// buffer passed on stdin-free: argv = <rows> <cols> <raw u8 file A> <raw u8 file B> <out file>.
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "orbslam3_amd/ORBextractor.h"
+#include "orbslam3_amd/ORBmatcher.h"
+
+static std::vector<unsigned char> slurp(const char* p, size_t n) {
+  std::vector<unsigned char> v(n);
+  FILE*                      f = fopen(p, "rb");
+  if (!f || fread(v.data(), 1, n, f) != n) {
+    fprintf(stderr, "cannot read %s\n", p);
+    exit(2);
+  }
+  fclose(f);
+  return v;
+}
+
+int main(int argc, char** argv) {
+  if (argc < 6) return 2;
+  const int rows = atoi(argv[1]), cols = atoi(argv[2]);
+  std::vector<unsigned char> A = slurp(argv[3], (size_t)rows * cols), B = slurp(argv[4], (size_t)rows * cols);
+  ORB_SLAM3::ORBextractor*   ext = new ORB_SLAM3::ORBextractor(1000, 1.2f, 8, 20, 7);  // src/Tracking.cc:576
+  std::vector<int>           vLapping = {0, 1000};                                      // mono convention, src/Frame.cc:451
+  orbx_cv::Mat               imA(rows, cols, orbx_cv::CV_8U, A.data()), imB(rows, cols, orbx_cv::CV_8U, B.data()), dA, dB;
+  std::vector<orbx_cv::KeyPoint> kA, kB;
+  int monoA = (*ext)(imA, orbx_cv::Mat(), kA, dA, vLapping);
+  int monoB = (*ext)(imB, orbx_cv::Mat(), kB, dB, vLapping);
+  std::vector<float> sf = ext->GetScaleFactors();
+  // brute-force SearchByBoW: one vocabulary node holding every feature
+  ORB_SLAM3::ORBmatcher                matcher(0.7f, true);
+  ORB_SLAM3::ORBmatcher::FeatureVector fA, fB;
+  for (size_t i = 0; i < kA.size(); i++) fA[0].push_back((unsigned)i);
+  for (size_t i = 0; i < kB.size(); i++) fB[0].push_back((unsigned)i);
+  std::vector<float> aA(kA.size()), aB(kB.size());
+  for (size_t i = 0; i < kA.size(); i++) aA[i] = kA[i].angle;
+  for (size_t i = 0; i < kB.size(); i++) aB[i] = kB[i].angle;
+  std::vector<int>           match;
+  std::vector<unsigned char> has(kA.size(), 1);
+  int                        nm = matcher.SearchByBoWArrays(dA, aA, fA, has, dB, aB, fB, match);
+  FILE*                      o  = fopen(argv[5], "wb");
+  fprintf(o, "%d %d %zu %zu %d %d %d %.9g %d\n", monoA, monoB, kA.size(), kB.size(), nm, ext->GetLevels(), ext->mvImagePyramid[7].cols, sf[7],
+          orbx_cv::Mat(dA.row(0)).cols);
+  for (size_t i = 0; i < kA.size(); i++) {
+    fprintf(o, "%.9g %.9g %.9g %.9g %d", kA[i].pt.x, kA[i].pt.y, kA[i].angle, kA[i].response, kA[i].octave);
+    for (int b = 0; b < 32; b++) fprintf(o, " %d", dA.ptr((int)i)[b]);
+    fprintf(o, "\n");
+  }
+  for (size_t j = 0; j < match.size(); j++) fprintf(o, "%d\n", match[j]);
+  fclose(o);
+  delete ext;
+  return 0;
+}

@@ -1,0 +1,52 @@
+"""The C++ drop-in adaptors (include/orbslam3_amd/*.h): compile on CPU, run against the oracle on GPU."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _build(tmp):
+    from orbslam3_cpp_fork_amd import build
+
+    so = build.build()
+    exe = os.path.join(tmp, "adaptor_smoke")
+    subprocess.check_call(
+        ["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), "-DORBX_NO_OPENCV", os.path.join(ROOT, "tests", "cpp", "adaptor_smoke.cpp"),
+         "-o", exe, "-L" + os.path.dirname(so), "-lorbx", "-Wl,-rpath," + os.path.dirname(so)]
+    )
+    return exe
+
+
+def test_adaptor_compiles(tmp_path):
+    assert os.path.exists(_build(str(tmp_path)))
+    # the C header alone is valid C
+    subprocess.check_call(["gcc", "-std=c99", "-fsyntax-only", "-x", "c", os.path.join(ROOT, "include", "orbx.h")])
+
+
+@pytest.mark.gpu
+def test_adaptor_matches_oracle(tmp_path, oracle):
+    from orbslam3_cpp_fork_amd import synth
+
+    exe = _build(str(tmp_path))
+    frames = synth.make_stream(480, 640, 2, camera_idx=6)
+    fa, fb, out = (str(tmp_path / n) for n in ("a.raw", "b.raw", "out.txt"))
+    frames[0].tofile(fa)
+    frames[1].tofile(fb)
+    subprocess.check_call([exe, "480", "640", fa, fb, out], timeout=300)
+    lines = open(out).read().split("\n")
+    hdr = lines[0].split()
+    oex = oracle.OracleExtractor(1000, 1.2, 8, 20, 7)
+    rcA, kA, dA = oex(frames[0], (0, 1000))
+    rcB, kB, dB = oex(frames[1], (0, 1000))
+    n, mq, mt = oracle.match_groups(dA, dB, kA["angle"], kB["angle"], th=50, ratio=0.7, check_ori=True)
+    assert [int(hdr[0]), int(hdr[1]), int(hdr[2]), int(hdr[3]), int(hdr[4]), int(hdr[5]), int(hdr[6])] == [rcA, rcB, len(kA), len(kB), n, 8, 179]
+    assert np.float32(hdr[7]) == oex.scale_tables()[0][7] and int(hdr[8]) == 32
+    for i in range(len(kA)):
+        v = lines[1 + i].split()
+        assert (np.float32(v[0]), np.float32(v[1]), np.float32(v[2]), np.float32(v[3]), int(v[4])) == (kA["x"][i], kA["y"][i], kA["angle"][i], kA["response"][i], kA["octave"][i])
+        assert [int(x) for x in v[5:37]] == dA[i].tolist()
+    got = [int(x) for x in lines[1 + len(kA): 1 + len(kA) + len(kB)]]
+    assert got == mt.tolist()

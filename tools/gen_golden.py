@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ from the CPU oracle.
+
+The reference ships no golden vectors for this path and cannot be run here (OpenCV / Eigen absent), so these
+fixtures pin the *oracle's* current behaviour ("parity unpinned" with respect to OpenCV): they guard the oracle
+and the HIP path against regressions, and give anyone with OpenCV 4.5.4 + the unmodified reference a concrete
+image -> (keypoints, descriptors) case to compare against.  Inputs are seeded synthetic frames.
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import oracle_py as O  # noqa: E402
+from orbslam3_cpp_fork_amd import synth  # noqa: E402
+
+out = os.path.join(ROOT, "tests", "golden")
+os.makedirs(out, exist_ok=True)
+
+frames = synth.make_stream(240, 320, 2, camera_idx=2)
+ex = O.OracleExtractor(500, 1.2, 8, 20, 7)
+res = []
+for lap in ((0, 1000), (0, 0)):
+    for f in range(2):
+        rc, k, d = ex(frames[f], lap)
+        res.append((rc, k, d))
+np.savez_compressed(
+    os.path.join(out, "extract_320x240_500.npz"),
+    frames=frames, params=np.array([500, 8, 20, 7], np.int32), scale=np.float32(1.2),
+    mono_lap1000_f0=res[0][0], kps_lap1000_f0=res[0][1], desc_lap1000_f0=res[0][2],
+    mono_lap1000_f1=res[1][0], kps_lap1000_f1=res[1][1], desc_lap1000_f1=res[1][2],
+    mono_lap0_f0=res[2][0], kps_lap0_f0=res[2][1], desc_lap0_f0=res[2][2],
+)
+k0, d0, k1, d1 = res[2][1], res[2][2], res[3][1], res[3][2]
+n, mq, mt = O.match_groups(d0, d1, k0["angle"], k1["angle"], th=50, ratio=0.7, strict_lt=False, check_ori=True)
+prev = np.stack([k0["x"], k0["y"]], 1).astype(np.float32)
+nw, m12, pm = O.match_window(d0, k0, d1, k1, prev, (0.0, 320.0, 0.0, 240.0), window=60, th=50, ratio=0.9, check_ori=True)
+np.savez_compressed(
+    os.path.join(out, "match_320x240_500.npz"),
+    kps0=k0, desc0=d0, kps1=k1, desc1=d1, bow_n=n, bow_match_t_of_q=mq, bow_match_q_of_t=mt,
+    win_n=nw, win_matches12=m12, win_prev_out=pm,
+)
+print("extract: %d / %d keypoints; bow matches %d; window matches %d" % (len(res[0][1]), len(res[1][1]), n, nw))
