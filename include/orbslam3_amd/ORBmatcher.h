@@ -13,7 +13,8 @@
 #include "../orbx.h"
 #include "cv_compat.h"
 
-namespace ORB_SLAM3 {
+// Own namespace: the reference keeps its ORB_SLAM3::ORBmatcher (Frame/KeyFrame-level methods) and forwards to this one.
+namespace ORB_SLAM3_AMD {
 
 class ORBmatcher {
  public:
@@ -98,5 +99,5 @@ class ORBmatcher {
   orbm_t* h_ = nullptr;
 };
 
-}  // namespace ORB_SLAM3
+}  // namespace ORB_SLAM3_AMD
 #endif

@@ -86,6 +86,8 @@ int  orbx_get_stage_ms(orbx_t* h, float* ms /* ORBX_NUM_STAGES */);
 int orbx_debug_blurred_level(orbx_t* h, int frame, int level, uint8_t* dst, size_t dst_step, int* rows, int* cols);
 int orbx_debug_level_candidates(orbx_t* h, int frame, int level, uint32_t* out, int cap);
 int orbx_debug_level_keypoints(orbx_t* h, int frame, int level, uint32_t* out, int cap);
+/* PMC calibration: stream nbytes of scratch memory with `width` (1, 4 or 16) bytes per lane per load. */
+int orbx_debug_calib_read(orbx_t* h, long long nbytes, int width);
 /* Device run of DistributeOctTree alone on caller-supplied candidates (host arrays). */
 int orbx_debug_octree_device(orbx_t* h, const uint32_t* cand, int n, int W, int H, int N, uint32_t* out, int* out_count);
 

@@ -538,6 +538,25 @@ int orbx_debug_octree_device(orbx_t* h, const uint32_t* cand, int n, int W, int 
   return 0;
 }
 
+// PMC calibration hook (see k_calib_read): reads `nbytes` of a scratch buffer with `width` bytes per lane per load.
+int orbx_debug_calib_read(orbx_t* h, long long nbytes, int width) {
+  if (!h || nbytes <= 0 || (width != 1 && width != 4 && width != 16)) return -2;
+  HIP_TRY(hipSetDevice(h->device));
+  DevBuf<uint8_t>  buf;
+  DevBuf<unsigned> sink;
+  if (buf.ensure((size_t)nbytes) || sink.ensure(1)) return -3;
+  HIP_TRY(hipMemsetAsync(buf.p, 1, (size_t)nbytes, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  const int grid = 2048;
+  if (width == 1) hipLaunchKernelGGL(orbx::k_calib_read<1>, dim3(grid), dim3(256), 0, h->stream, buf.p, nbytes, sink.p);
+  if (width == 4) hipLaunchKernelGGL(orbx::k_calib_read<4>, dim3(grid), dim3(256), 0, h->stream, buf.p, nbytes, sink.p);
+  if (width == 16) hipLaunchKernelGGL(orbx::k_calib_read<16>, dim3(grid), dim3(256), 0, h->stream, buf.p, nbytes, sink.p);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  buf.release(), sink.release();
+  return 0;
+}
+
 void orbx_set_profiling(orbx_t* h, int enable) {
   if (!h) return;
   h->profiling = enable != 0;

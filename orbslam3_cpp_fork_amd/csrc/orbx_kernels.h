@@ -628,5 +628,25 @@ __global__ __launch_bounds__(256) void k_orient_describe(Bufs b, FrameGeom g, co
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// PMC calibration: stream `n` bytes with W bytes per lane per load (W = 1, 4, 16) and fold them into one word,
+// so that rocprofv3's FETCH_SIZE can be compared with a known byte count for each access width this library
+// uses (MI355X_MICROARCH.md, HBM: the counter is only calibrated for 16 B/lane streams).
+// ------------------------------------------------------------------------------------------------
+template <int W>
+__global__ __launch_bounds__(256) void k_calib_read(const uint8_t* __restrict__ src, long long n, unsigned* sink) {
+  const long long stride = (long long)gridDim.x * 256 * W;
+  unsigned        acc    = 0;
+  for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * W; i + W <= n; i += stride) {
+    if (W == 1) acc += src[i];
+    if (W == 4) acc += *reinterpret_cast<const unsigned*>(src + i);
+    if (W == 16) {
+      const uint4 v = *reinterpret_cast<const uint4*>(src + i);
+      acc += v.x ^ v.y ^ v.z ^ v.w;
+    }
+  }
+  if (acc == 0x12345677u) *sink = acc;  // keeps the loads alive
+}
+
 }  // namespace orbx
 #endif

@@ -82,7 +82,9 @@ def make_stream(height, width, n_frames, camera_idx=0, max_shift=8):
     seed = BASE_SEED + 1000 * camera_idx
     rng = np.random.Generator(np.random.PCG64(seed + 7))
     margin = max_shift * n_frames + 8
-    world = make_world(height + margin, width + margin, seed)
+    # keep the rectangle (corner) density of a long stream's world at that of a short one
+    n_rects = max(400, int(5e-4 * (height + margin) * (width + margin)))
+    world = make_world(height + margin, width + margin, seed, n_rects=n_rects)
     frames = np.empty((n_frames, height, width), np.uint8)
     ox = oy = 0
     for f in range(n_frames):

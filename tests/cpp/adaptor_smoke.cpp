@@ -31,8 +31,8 @@ int main(int argc, char** argv) {
   int monoB = (*ext)(imB, orbx_cv::Mat(), kB, dB, vLapping);
   std::vector<float> sf = ext->GetScaleFactors();
   // brute-force SearchByBoW: one vocabulary node holding every feature
-  ORB_SLAM3::ORBmatcher                matcher(0.7f, true);
-  ORB_SLAM3::ORBmatcher::FeatureVector fA, fB;
+  ORB_SLAM3_AMD::ORBmatcher                matcher(0.7f, true);
+  ORB_SLAM3_AMD::ORBmatcher::FeatureVector fA, fB;
   for (size_t i = 0; i < kA.size(); i++) fA[0].push_back((unsigned)i);
   for (size_t i = 0; i < kB.size(); i++) fB[0].push_back((unsigned)i);
   std::vector<float> aA(kA.size()), aB(kB.size());
