@@ -88,7 +88,7 @@ struct orbx_extractor {
   orbx::Bufs      bufs{};
   DevBuf<uint8_t> dPyr, dBlur, dQv, dStage, dDescOut;
   DevBuf<int2>    dXtab, dYtab;
-  DevBuf<int>     dCellSlot, dCellCount, dOrdA, dOrdB, dNodeOfA, dNodeOfB, dP, dD, dDIndex, dNCh, dPushOff, dMultiOff, dKeptRank, dVA,
+  DevBuf<int>     dCellOrder, dCellSlot, dCellCount, dOrdA, dOrdB, dNodeOfA, dNodeOfB, dP, dD, dDIndex, dNCh, dPushOff, dMultiOff, dKeptRank, dVA,
       dVB, dCandCount, dLvlCount, dOutIdx, dCounts;
   DevBuf<uint32_t>           dSlots, dCand, dLvlKp;
   DevBuf<orbx::OtNode>       dNodesA, dNodesB;
@@ -97,6 +97,7 @@ struct orbx_extractor {
   DevBuf<orbx::PatternTab>   dPattern;
   DevBuf<orbx::KpRec>        dKpOut;
   int                        stagePitch = 0;
+  int                        fastGrid   = 0;
 
   int makeGeometry(int rows, int cols);
   int ensureWorkspace(int rows, int cols, int B);
@@ -218,6 +219,33 @@ int orbx_extractor::makeGeometry(int rows, int cols) {
   g.totalBlurTiles = tileBase;
   g.pyrBytes       = alignUp(pyrOff, 256);
   g.blurBytes      = alignUp(blurOff, 256);
+  // FAST launch order: cell rows dealt round-robin to the 8 XCDs (block b runs on XCD b % 8)
+  std::vector<int> cellOrder;
+  {
+    // longest-row-first onto the least loaded XCD: equal cell counts per XCD (rows differ from 17 to 4 cells at VGA)
+    struct Row {
+      int level, i, cells;
+    };
+    std::vector<Row> rows;
+    for (int l = 0; l < nlevels; l++)
+      for (int i = 0; i < g.lv[l].nRows; i++) rows.push_back({l, i, g.lv[l].nCols});
+    std::stable_sort(rows.begin(), rows.end(), [](const Row& a, const Row& b) { return a.cells > b.cells; });
+    std::vector<std::vector<int>> perXcd(8);
+    for (const Row& r : rows) {
+      int best = 0;
+      for (int x = 1; x < 8; x++)
+        if (perXcd[x].size() < perXcd[best].size()) best = x;
+      for (int j = 0; j < r.cells; j++) perXcd[best].push_back(g.lv[r.level].cellBase + r.i * g.lv[r.level].nCols + j);
+    }
+    size_t per = 0;
+    for (auto& v : perXcd) per = std::max(per, v.size());
+    cellOrder.assign(per * 8, -1);
+    for (int x = 0; x < 8; x++)
+      for (size_t k = 0; k < perXcd[x].size(); k++) cellOrder[k * 8 + x] = perXcd[x][k];
+    fastGrid = (int)cellOrder.size();
+  }
+  if (dCellOrder.ensure(cellOrder.size() + 1)) return -3;
+  HIP_TRY(hipMemcpy(dCellOrder.p, cellOrder.data(), cellOrder.size() * sizeof(int), hipMemcpyHostToDevice));
   // upload tables
   if (dXtab.ensure(xt.size() + 1) || dYtab.ensure(yt.size() + 1) || dCellSlot.ensure(cellSlot.size() + 1)) return -3;
   HIP_TRY(hipMemcpy(dXtab.p, xt.data(), xt.size() * sizeof(int2), hipMemcpyHostToDevice));
@@ -244,7 +272,7 @@ int orbx_extractor::ensureWorkspace(int rows, int cols, int B) {
       dLvlCount.ensure(nb * g.nlevels) || dOutIdx.ensure(nb * g.totalKp))
     return -3;
   orbx::Bufs& b = bufs;
-  b.pyr = dPyr.p, b.blur = dBlur.p, b.xtab = dXtab.p, b.ytab = dYtab.p, b.cellSlot = dCellSlot.p, b.slots = dSlots.p;
+  b.pyr = dPyr.p, b.blur = dBlur.p, b.xtab = dXtab.p, b.ytab = dYtab.p, b.cellSlot = dCellSlot.p, b.cellOrder = dCellOrder.p, b.slots = dSlots.p;
   b.cellCount = dCellCount.p, b.cand = dCand.p, b.ordA = dOrdA.p, b.ordB = dOrdB.p, b.nodeOfA = dNodeOfA.p, b.nodeOfB = dNodeOfB.p;
   b.P = dP.p, b.qv = dQv.p, b.nodesA = dNodesA.p, b.nodesB = dNodesB.p, b.startCnt = dStartCnt.p, b.endCnt = dEndCnt.p, b.D = dD.p;
   b.dIndex = dDIndex.p, b.nCh = dNCh.p, b.pushOff = dPushOff.p, b.multiOff = dMultiOff.p, b.keptRank = dKeptRank.p, b.vA = dVA.p;
@@ -274,20 +302,24 @@ int orbx_extractor::run(const uint8_t* d_imgs, int B, int rows, int cols, size_t
   hipEvent_t* ev = this->ev[profCount % kProfSlots];
   if (prof) HIP_TRY(hipEventRecord(ev[0], s));
   for (int l = 1; l < g.nlevels; l++) {
-    dim3 grid((g.lv[l].w + 255) / 256, (g.lv[l].h + 3) / 4, B), block(64, 4, 1);
+    dim3 grid((g.lv[l].w + kRsTileW - 1) / kRsTileW, (g.lv[l].h + kRsTileH - 1) / kRsTileH, B), block(256, 1, 1);
     hipLaunchKernelGGL(k_resize_level, grid, block, 0, s, b, g, l);
   }
   if (prof) HIP_TRY(hipEventRecord(ev[1], s));
-  hipLaunchKernelGGL(k_fast_cells, dim3(g.totalCells, B), dim3(256), 0, s, b, g, std::min(std::max(iniTh, 0), 255),
+  hipLaunchKernelGGL(k_fast_cells, dim3(fastGrid, B), dim3(256), 0, s, b, g, std::min(std::max(iniTh, 0), 255),
                      std::min(std::max(minTh, 0), 255));
   if (prof) HIP_TRY(hipEventRecord(ev[2], s));
   hipLaunchKernelGGL(k_octree, dim3(g.nlevels, B), dim3(kOctThreads), 0, s, b, g);
   if (prof) HIP_TRY(hipEventRecord(ev[3], s));
   hipLaunchKernelGGL(k_layout, dim3(B), dim3(256), 0, s, b, g, lap0, lap1, d_counts, cap);
   if (prof) HIP_TRY(hipEventRecord(ev[4], s));
-  hipLaunchKernelGGL(k_blur_levels, dim3(g.totalBlurTiles, B), dim3(256), 0, s, b, g);
+  hipLaunchKernelGGL(k_blur_levels, dim3(8 * ((g.totalBlurTiles + 7) / 8), B), dim3(256), 0, s, b, g);
   if (prof) HIP_TRY(hipEventRecord(ev[5], s));
-  hipLaunchKernelGGL(k_orient_describe, dim3((g.totalKp + 3) / 4, B), dim3(256), 0, s, b, g, dPattern.p, d_counts, d_kps, d_desc, cap);
+  {
+    const int nbPerFrame = (g.totalKp + 3) / 4;
+    hipLaunchKernelGGL(k_orient_describe, dim3(8 * ((B + 7) / 8) * nbPerFrame), dim3(256), 0, s, b, g, dPattern.p, d_counts, d_kps, d_desc, cap, B,
+                       nbPerFrame);
+  }
   if (prof) {
     HIP_TRY(hipEventRecord(ev[6], s));
     profCount++;
@@ -362,7 +394,7 @@ void orbx_destroy(orbx_t* h) {
     for (auto& slot : h->ev)
       for (auto& e : slot) hipEventDestroy(e);
   h->dPyr.release(), h->dBlur.release(), h->dQv.release(), h->dStage.release(), h->dDescOut.release(), h->dXtab.release(), h->dYtab.release();
-  h->dCellSlot.release(), h->dCellCount.release(), h->dOrdA.release(), h->dOrdB.release(), h->dNodeOfA.release(), h->dNodeOfB.release();
+  h->dCellOrder.release(), h->dCellSlot.release(), h->dCellCount.release(), h->dOrdA.release(), h->dOrdB.release(), h->dNodeOfA.release(), h->dNodeOfB.release();
   h->dP.release(), h->dD.release(), h->dDIndex.release(), h->dNCh.release(), h->dPushOff.release(), h->dMultiOff.release();
   h->dKeptRank.release(), h->dVA.release(), h->dVB.release(), h->dCandCount.release(), h->dLvlCount.release(), h->dOutIdx.release();
   h->dCounts.release(), h->dSlots.release(), h->dCand.release(), h->dLvlKp.release(), h->dNodesA.release(), h->dNodesB.release();

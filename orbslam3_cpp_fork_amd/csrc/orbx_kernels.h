@@ -35,6 +35,7 @@ struct Bufs {
   const int2*    xtab;  // resize tables: .x = source index, .y = a0 | a1 << 16 (Q11)
   const int2*    ytab;
   const int*     cellSlot;   // [totalCells] slot base of each cell inside the frame's slot array
+  const int*     cellOrder;  // [fastGrid] XCD-aware launch order of the FAST cells (-1 = padding)
   uint32_t*      slots;      // [B][totalSlots] per-cell candidate slots written by FAST
   int*           cellCount;  // [B][totalCells]
   // quadtree workspace, per frame: point arrays [totalSlots], node arrays [totalNodes]
@@ -65,36 +66,70 @@ __device__ __forceinline__ const uint8_t* level_raw(const Bufs& b, const FrameGe
 // Tables (source index + Q11 weights) are built on the host with the exact float/double recipe, so
 // the kernel is integer-only.  Thread = 4 adjacent destination pixels, one 32-bit store.
 // ------------------------------------------------------------------------------------------------
+// Workgroup = 128 x 16 destination tile.  The source footprint (<= 160 x 24 px at scale 1.2) is staged in LDS
+// with aligned 32-bit loads, then every thread produces 2 rows x 4 px from LDS bytes.
+constexpr int kRsTileW = 128, kRsTileH = 16, kRsLdsW = 176, kRsLdsH = 24;
+
 __global__ __launch_bounds__(256) void k_resize_level(Bufs b, FrameGeom g, int level) {
-  const LevelGeom& L  = g.lv[level];
-  const LevelGeom& Ls = g.lv[level - 1];
-  const int        f  = blockIdx.z;
-  const int        dx = (blockIdx.x * 64 + threadIdx.x) * 4;
-  const int        dy = blockIdx.y * 4 + threadIdx.y;
-  if (dx >= L.w || dy >= L.h) return;
-  int            sp;
-  const uint8_t* S   = level_raw(b, g, level - 1, f, &sp);
-  uint8_t*       D   = b.pyr + (long long)f * g.pyrBytes + L.pyrOff + (long long)dy * L.pitch;
-  const int2     yt  = b.ytab[L.ytabOff + dy];
-  const int      sy0 = min(max(yt.x, 0), Ls.h - 1), sy1 = min(max(yt.x + 1, 0), Ls.h - 1);
-  const int      b0 = (short)(yt.y & 0xffff), b1 = yt.y >> 16;
-  const uint8_t *S0 = S + (long long)sy0 * sp, *S1 = S + (long long)sy1 * sp;
-  uint32_t       out = 0;
+  __shared__ __align__(16) uint8_t src[kRsLdsH][kRsLdsW];
+  const LevelGeom& L   = g.lv[level];
+  const LevelGeom& Ls  = g.lv[level - 1];
+  const int        f   = blockIdx.z, tid = threadIdx.x;
+  const int        dx0 = blockIdx.x * kRsTileW, dy0 = blockIdx.y * kRsTileH;
+  const int        dxl = min(dx0 + kRsTileW, L.w) - 1, dyl = min(dy0 + kRsTileH, L.h) - 1;
+  int              sp;
+  const uint8_t*   S   = level_raw(b, g, level - 1, f, &sp);
+  // source footprint of the tile (tables are monotone)
+  const int sxa = b.xtab[L.xtabOff + dx0].x & ~3;
+  const int sxb = min(b.xtab[L.xtabOff + dxl].x + 1, Ls.w - 1);
+  const int sya = min(max(b.ytab[L.ytabOff + dy0].x, 0), Ls.h - 1);
+  const int syb = min(max(b.ytab[L.ytabOff + dyl].x + 1, 0), Ls.h - 1);
+  const int nw4 = (sxb - sxa + 4) >> 2, nrow = syb - sya + 1;  // <= 44 dwords x 24 rows
+  const bool al4 = ((sp & 3) == 0) && ((reinterpret_cast<uintptr_t>(S) & 3) == 0);
+  for (int idx = tid; idx < nw4 * nrow; idx += 256) {
+    const int      r = idx / nw4, c = (idx - r * nw4) * 4;
+    const uint8_t* p = S + (long long)(sya + r) * sp + sxa + c;
+    uint32_t       v;
+    if (al4) {
+      v = *reinterpret_cast<const uint32_t*>(p);  // may run past Ls.w inside the padded/aligned row: unused bytes
+    } else {
+      v = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        if (sxa + c + k < Ls.w) v |= (uint32_t)p[k] << (8 * k);
+    }
+    *reinterpret_cast<uint32_t*>(&src[r][c]) = v;
+  }
+  __syncthreads();
+  const int dx = dx0 + (tid & 31) * 4;
+  if (dx >= L.w) return;
+  int  sx[4], a0[4], a1[4];
 #pragma unroll
   for (int k = 0; k < 4; k++) {
-    int x = dx + k;
-    if (x < L.w) {
-      const int2 xt  = b.xtab[L.xtabOff + x];
-      const int  sx  = xt.x;
-      const int  sx1 = min(sx + 1, Ls.w - 1);
-      const int  a0 = (short)(xt.y & 0xffff), a1 = xt.y >> 16;
-      const int  h0 = S0[sx] * a0 + S0[sx1] * a1;
-      const int  h1 = S1[sx] * a0 + S1[sx1] * a1;
-      const int  v  = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+    const int2 xt = b.xtab[L.xtabOff + min(dx + k, L.w - 1)];
+    sx[k] = xt.x - sxa;
+    a0[k] = (short)(xt.y & 0xffff);
+    a1[k] = xt.y >> 16;
+  }
+#pragma unroll
+  for (int rr = 0; rr < 2; rr++) {
+    const int dy = dy0 + (tid >> 5) * 2 + rr;
+    if (dy >= L.h) break;
+    const int2 yt = b.ytab[L.ytabOff + dy];
+    const int  r0 = min(max(yt.x, 0), Ls.h - 1) - sya, r1 = min(max(yt.x + 1, 0), Ls.h - 1) - sya;
+    const int  b0 = (short)(yt.y & 0xffff), b1 = yt.y >> 16;
+    uint32_t   out = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int x1 = min(sx[k] + 1, Ls.w - 1 - sxa);  // second tap clamps at the last source column (weight 0 there)
+      const int h0 = src[r0][sx[k]] * a0[k] + src[r0][x1] * a1[k];
+      const int h1 = src[r1][sx[k]] * a0[k] + src[r1][x1] * a1[k];
+      const int v  = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
       out |= (uint32_t)(v & 0xff) << (8 * k);
     }
+    // pitch is a multiple of 64: lanes past L.w write into the row's padding
+    *reinterpret_cast<uint32_t*>(b.pyr + (long long)f * g.pyrBytes + L.pyrOff + (long long)dy * L.pitch + dx) = out;
   }
-  *reinterpret_cast<uint32_t*>(D + dx) = out;  // pitch is a multiple of 64: the padded tail is writable
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -107,6 +142,16 @@ __global__ __launch_bounds__(256) void k_resize_level(Bufs b, FrameGeom g, int l
 // s_t, with neighbours outside the cell's 3-px-inset interior counting as 0 (they are never scored
 // by cv::FAST on the sub-image).  Output order is row-major, as cv::FAST emits.
 // ------------------------------------------------------------------------------------------------
+// XCD-aware work mapping.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share an L2), so
+// giving XCD x the contiguous range [x * per, (x + 1) * per) of work items keeps spatial neighbours -- which share
+// cache lines and halos -- behind ONE L2 instead of eight.  The grid is padded to 8 * per; returns -1 for padding.
+// Placement only affects speed, never results.
+__device__ __forceinline__ int xcd_item(int block, int nitems) {
+  const int per  = (nitems + 7) >> 3;
+  const int item = (block & 7) * per + (block >> 3);
+  return ((block >> 3) < per && item < nitems) ? item : -1;
+}
+
 // idx / d for 0 <= idx < 65536, 1 <= d <= 256 with one multiply-high: m = floor(2^32 / d) + 1.
 __device__ __forceinline__ int div_magic(unsigned idx, unsigned m) { return m ? (int)__umulhi(idx, m) : (int)idx; }  // m == 0 encodes d == 1
 
@@ -157,8 +202,12 @@ __global__ __launch_bounds__(256) void k_fast_cells(Bufs b, FrameGeom g, int ini
   __shared__ int     wavePre[2][24][4];  // per (threshold, iteration, wave) keypoint counts -> exclusive offsets
   __shared__ int     selTh, selTot, candCount;
   __shared__ unsigned short candList[(kFastTileMax - 6) * (kFastTileMax - 6)];
-  const int          cell = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
-  int                level = 0;
+  // block -> cell through a host-built order table: whole cell ROWS are dealt round-robin to the 8 XCDs, so that
+  // horizontally adjacent cells (which share 128-B lines and the 6-px overlap) sit behind one L2 while the
+  // per-XCD amount of work stays balanced across pyramid levels.  -1 = padding.
+  const int          cell = b.cellOrder[blockIdx.x], f = blockIdx.y, tid = threadIdx.x;
+  if (cell < 0) return;
+  int level = 0;
   while (level + 1 < g.nlevels && cell >= g.lv[level + 1].cellBase) level++;
   const LevelGeom& L  = g.lv[level];
   const int        ci = cell - L.cellBase;
@@ -471,7 +520,8 @@ __device__ __forceinline__ void blur_load10(const uint8_t* __restrict__ row, int
 
 __global__ __launch_bounds__(256) void k_blur_levels(Bufs b, FrameGeom g) {
   const int f = blockIdx.y, tid = threadIdx.x;
-  int       t = blockIdx.x, level = 0;
+  int       t = xcd_item(blockIdx.x, g.totalBlurTiles), level = 0;
+  if (t < 0) return;
   while (level + 1 < g.nlevels && t >= g.lv[level + 1].blurTileBase) level++;
   const LevelGeom& L      = g.lv[level];
   const int        groups = (L.w + 3) >> 2;
@@ -545,9 +595,13 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {  // cv::fast
 __constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};  // src/ORBextractor.cc:448-464
 
 __global__ __launch_bounds__(256) void k_orient_describe(Bufs b, FrameGeom g, const PatternTab* __restrict__ pat, const int* counts,
-                                                          KpRec* kps, uint8_t* desc, int cap) {
-  const int f = blockIdx.y, lane = threadIdx.x & 63;
-  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+                                                          KpRec* kps, uint8_t* desc, int cap, int nframes, int nbPerFrame) {
+  // 1-D grid with frame -> XCD affinity: all workgroups of frame f run on XCD f % 8 (blocks b, b + 8, ... share an
+  // L2), so the raw + blurred levels of a frame (1.9 MB at VGA) are pulled into ONE 4-MiB L2 instead of all eight.
+  const int lane = threadIdx.x & 63;
+  const int q = blockIdx.x >> 3, f = (blockIdx.x & 7) + 8 * (q / nbPerFrame);
+  if (f >= nframes) return;
+  const int i = (q % nbPerFrame) * 4 + (threadIdx.x >> 6);
   const int n = counts[2 * f];
   if (i >= n) return;
   const int* lc = b.lvlCount + (long long)f * g.nlevels;
