@@ -75,6 +75,9 @@ struct orbx_extractor {
   std::vector<int>   quota;
   int                device = 0;
   hipStream_t        stream = nullptr;
+  hipStream_t        stream2 = nullptr;  // side stream: the blur runs beside FAST -> quadtree -> layout
+  hipEvent_t         evFork = nullptr, evJoin = nullptr, evBlur0 = nullptr, evBlur1 = nullptr;
+  float              blurMsAcc = 0.f;
   bool               profiling = false;
   static constexpr int kProfSlots = 32;  // ring of event sets: one per profiled batch
   hipEvent_t         ev[kProfSlots][ORBX_NUM_STAGES] = {};
@@ -305,6 +308,14 @@ int orbx_extractor::run(const uint8_t* d_imgs, int B, int rows, int cols, size_t
     dim3 grid((g.lv[l].w + kRsTileW - 1) / kRsTileW, (g.lv[l].h + kRsTileH - 1) / kRsTileH, B), block(256, 1, 1);
     hipLaunchKernelGGL(k_resize_level, grid, block, 0, s, b, g, l);
   }
+  // fork: the blur only needs the pyramid; it runs on the side stream while FAST -> quadtree -> layout (all
+  // latency-bound, leaving issue slots idle) proceed on the caller's stream, and joins before the descriptors.
+  HIP_TRY(hipEventRecord(evFork, s));
+  HIP_TRY(hipStreamWaitEvent(stream2, evFork, 0));
+  if (prof) HIP_TRY(hipEventRecord(evBlur0, stream2));
+  hipLaunchKernelGGL(k_blur_levels, dim3(8 * ((g.totalBlurTiles + 7) / 8), B), dim3(256), 0, stream2, b, g);
+  if (prof) HIP_TRY(hipEventRecord(evBlur1, stream2));
+  HIP_TRY(hipEventRecord(evJoin, stream2));
   if (prof) HIP_TRY(hipEventRecord(ev[1], s));
   hipLaunchKernelGGL(k_fast_cells, dim3(fastGrid, B), dim3(256), 0, s, b, g, std::min(std::max(iniTh, 0), 255),
                      std::min(std::max(minTh, 0), 255));
@@ -313,7 +324,7 @@ int orbx_extractor::run(const uint8_t* d_imgs, int B, int rows, int cols, size_t
   if (prof) HIP_TRY(hipEventRecord(ev[3], s));
   hipLaunchKernelGGL(k_layout, dim3(B), dim3(256), 0, s, b, g, lap0, lap1, d_counts, cap);
   if (prof) HIP_TRY(hipEventRecord(ev[4], s));
-  hipLaunchKernelGGL(k_blur_levels, dim3(8 * ((g.totalBlurTiles + 7) / 8), B), dim3(256), 0, s, b, g);
+  HIP_TRY(hipStreamWaitEvent(s, evJoin, 0));  // join (stage 4 = time the main stream waits for the blur)
   if (prof) HIP_TRY(hipEventRecord(ev[5], s));
   {
     const int nbPerFrame = (g.totalKp + 3) / 4;
@@ -369,6 +380,14 @@ int orbx_create(orbx_t** out, int nfeatures, float scale_factor, int nlevels, in
     delete h;
     return -3;
   }
+  if (hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&h->evFork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&h->evJoin, hipEventDisableTiming) != hipSuccess || hipEventCreate(&h->evBlur0) != hipSuccess ||
+      hipEventCreate(&h->evBlur1) != hipSuccess) {
+    g_err = "hipStreamCreate/hipEventCreate (side stream) failed";
+    delete h;
+    return -3;
+  }
   if (h->dPattern.ensure(1)) {
     delete h;
     return -3;
@@ -386,10 +405,16 @@ int orbx_create(orbx_t** out, int nfeatures, float scale_factor, int nlevels, in
 void orbx_destroy(orbx_t* h) {
   if (!h) return;
   hipSetDevice(h->device);
+  if (h->stream2) {
+    hipStreamSynchronize(h->stream2);
+    hipStreamDestroy(h->stream2);
+  }
   if (h->stream) {
     hipStreamSynchronize(h->stream);
     hipStreamDestroy(h->stream);
   }
+  for (hipEvent_t e : {h->evFork, h->evJoin, h->evBlur0, h->evBlur1})
+    if (e) hipEventDestroy(e);
   if (h->evValid)
     for (auto& slot : h->ev)
       for (auto& e : slot) hipEventDestroy(e);

@@ -197,15 +197,15 @@ __device__ __forceinline__ int fast_score(const uint8_t (*tile)[kFastTileMax], i
 }
 
 __global__ __launch_bounds__(256) void k_fast_cells(Bufs b, FrameGeom g, int iniTh, int minTh) {
-  __shared__ __align__(16) uint8_t tile[kFastTileMax][kFastTileMax];
-  __shared__ __align__(16) uint8_t score[kFastTileMax][kFastTileMax];
-  __shared__ int     wavePre[2][24][4];  // per (threshold, iteration, wave) keypoint counts -> exclusive offsets
-  __shared__ int     selTh, selTot, candCount;
-  __shared__ unsigned short candList[(kFastTileMax - 6) * (kFastTileMax - 6)];
-  // block -> cell through a host-built order table: whole cell ROWS are dealt round-robin to the 8 XCDs, so that
-  // horizontally adjacent cells (which share 128-B lines and the 6-px overlap) sit behind one L2 while the
-  // per-XCD amount of work stays balanced across pyramid levels.  -1 = padding.
-  const int          cell = b.cellOrder[blockIdx.x], f = blockIdx.y, tid = threadIdx.x;
+  constexpr int                     kMaxInt = (kFastTileMax - 6) * (kFastTileMax - 6);  // interior pixels of the largest tile
+  __shared__ __align__(16) uint8_t  tile[kFastTileMax][kFastTileMax];   // pixels; after scoring: NMS flag bits
+  __shared__ __align__(16) uint8_t  score[kFastTileMax][kFastTileMax];  // corner score (0 = not a corner at lowTh)
+  __shared__ unsigned short         candList[kMaxInt];                  // pass-1 survivors (pixel index in the interior)
+  __shared__ unsigned short         kpList[kMaxInt / 2 + 64];           // NMS survivors under either threshold
+  __shared__ int                    candCount, kpCount, cnt1, cnt2;
+  // block -> cell through a host-built order table: whole cell ROWS are dealt to the 8 XCDs (balanced by cell count),
+  // so that horizontally adjacent cells (which share 128-B lines and the 6-px overlap) sit behind one L2.  -1 = padding.
+  const int cell = b.cellOrder[blockIdx.x], f = blockIdx.y, tid = threadIdx.x;
   if (cell < 0) return;
   int level = 0;
   while (level + 1 < g.nlevels && cell >= g.lv[level + 1].cellBase) level++;
@@ -227,14 +227,14 @@ __global__ __launch_bounds__(256) void k_fast_cells(Bufs b, FrameGeom g, int ini
   }
   int            pitch;
   const uint8_t* img = level_raw(b, g, level, f, &pitch) + (long long)iniY * pitch + iniX;
-  const unsigned mIw = 0xffffffffu / (unsigned)iw + 1u;  // interior-width divider for idx -> (row, col)
+  const unsigned mIw = iw == 1 ? 0u : 0xffffffffu / (unsigned)iw + 1u;  // interior-width divider for idx -> (row, col)
   {
     // tile load: 4 pixels per thread where the row is 4-byte aligned in memory, bytes otherwise
-    const int      tw4  = (tw + 3) >> 2;
-    const unsigned mT4  = 0xffffffffu / (unsigned)tw4 + 1u;
-    const bool     al4  = ((pitch & 3) == 0) && ((reinterpret_cast<uintptr_t>(img) & 3) == 0);
+    const int      tw4 = (tw + 3) >> 2;
+    const unsigned mT4 = 0xffffffffu / (unsigned)tw4 + 1u;
+    const bool     al4 = ((pitch & 3) == 0) && ((reinterpret_cast<uintptr_t>(img) & 3) == 0);
     for (int idx = tid; idx < tw4 * th; idx += 256) {
-      const int y = div_magic(idx, mT4), x = (idx - y * tw4) * 4;
+      const int      y = div_magic(idx, mT4), x = (idx - y * tw4) * 4;
       const uint8_t* src = img + (long long)y * pitch + x;
       uint32_t       v;
       if (al4 && x + 4 <= tw) {
@@ -248,31 +248,38 @@ __global__ __launch_bounds__(256) void k_fast_cells(Bufs b, FrameGeom g, int ini
       *reinterpret_cast<uint32_t*>(&tile[y][x])  = v;  // kFastTileMax is a multiple of 4: aligned; spill past tw stays inside the row
       *reinterpret_cast<uint32_t*>(&score[y][x]) = 0;
     }
+    if (tid == 0) candCount = 0, kpCount = 0, cnt1 = 0, cnt2 = 0;
   }
   __syncthreads();
   const int npix  = iw * ih;
   const int lowTh = max(min(iniTh, minTh), 1);
-  // Pass 1 -- cheap necessary condition + compaction.  A 9-arc of the 16-pixel circle always contains two
-  // ADJACENT compass points (0, 4, 8, 12), so a pixel can only score >= lowTh if two adjacent compass pixels are
-  // both darker than v - lowTh or both brighter than v + lowTh.  Survivors are appended (any order) to an LDS
-  // list so that pass 2 evaluates the full score with all lanes busy.
-  if (tid == 0) candCount = 0;
-  __syncthreads();
+  const int lane  = tid & 63;
+  // Pass 1 -- necessary condition + compaction.  A 9-arc of the 16-pixel circle always contains 4 CONSECUTIVE even
+  // circle positions (0, 2, .., 14), so a pixel can only score >= lowTh if four consecutive even positions are all
+  // darker than v - lowTh or all brighter than v + lowTh.  Survivors go (any order) to an LDS list so that the
+  // full score below runs with all lanes busy.
   for (int idx = tid; idx < ((npix + 63) & ~63); idx += 256) {
     bool keep = false;
     if (idx < npix) {
       const int q = div_magic(idx, mIw), y = 3 + q, x = 3 + idx - q * iw;
       const int v = tile[y][x];
-      const int d0 = v - tile[y + 3][x], d4 = v - tile[y][x + 3], d8 = v - tile[y - 3][x], d12 = v - tile[y][x - 3];
-      const bool k0 = d0 > lowTh, k4 = d4 > lowTh, k8 = d8 > lowTh, k12 = d12 > lowTh;
-      const bool b0 = -d0 > lowTh, b4 = -d4 > lowTh, b8 = -d8 > lowTh, b12 = -d12 > lowTh;
-      keep = (k0 && k4) || (k4 && k8) || (k8 && k12) || (k12 && k0) || (b0 && b4) || (b4 && b8) || (b8 && b12) || (b12 && b0);
+      const int lo = v - lowTh, hi = v + lowTh;
+      const int p0 = tile[y + 3][x], p2 = tile[y + 2][x + 2], p4 = tile[y][x + 3], p6 = tile[y - 2][x + 2];
+      const int p8 = tile[y - 3][x], p10 = tile[y - 2][x - 2], p12 = tile[y][x - 3], p14 = tile[y + 2][x - 2];
+      unsigned dk = (p0 < lo) | ((p2 < lo) << 1) | ((p4 < lo) << 2) | ((p6 < lo) << 3) | ((p8 < lo) << 4) | ((p10 < lo) << 5) |
+                    ((p12 < lo) << 6) | ((p14 < lo) << 7);
+      unsigned br = (p0 > hi) | ((p2 > hi) << 1) | ((p4 > hi) << 2) | ((p6 > hi) << 3) | ((p8 > hi) << 4) | ((p10 > hi) << 5) |
+                    ((p12 > hi) << 6) | ((p14 > hi) << 7);
+      dk |= dk << 8, br |= br << 8;  // cyclic
+      dk &= dk >> 1, dk &= dk >> 2;  // bit i = positions i..i+3 all set
+      br &= br >> 1, br &= br >> 2;
+      keep = ((dk | br) & 0xffu) != 0;
     }
     const unsigned long long bal = __ballot(keep);
     int                      base = 0;
-    if ((tid & 63) == 0 && bal) base = atomicAdd(&candCount, __popcll(bal));
+    if (lane == 0 && bal) base = atomicAdd(&candCount, __popcll(bal));
     base = __shfl(base, 0, 64);
-    if (keep) candList[base + __popcll(bal & ((1ull << (tid & 63)) - 1ull))] = (unsigned short)idx;
+    if (keep) candList[base + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)idx;
   }
   __syncthreads();
   // Pass 2 -- full corner score of the survivors
@@ -284,14 +291,12 @@ __global__ __launch_bounds__(256) void k_fast_cells(Bufs b, FrameGeom g, int ini
     score[y][x] = (uint8_t)(s >= lowTh ? s : 0);  // scores below both thresholds are never corners
   }
   __syncthreads();
-  // strict 3x3 NMS under both thresholds; per-(iteration, wave) counts.  (iteration, wave, lane) order is
-  // the row-major pixel order cv::FAST emits in.
-  const int lane = tid & 63, wave = tid >> 6;
-  const int niter = (npix + 255) >> 8;  // <= 20 (interior <= 71 x 71)
-  for (int it = 0; it < niter; it++) {
-    const int idx = it * 256 + tid;
-    bool      f1 = false, f2 = false;
-    if (idx < npix) {
+  // Pass 3 -- strict 3x3 NMS under both thresholds, over the survivors only.  Flags go to a sparse list.
+  for (int k = tid; k < ((ncand + 63) & ~63); k += 256) {
+    bool f1 = false, f2 = false;
+    int  idx = 0;
+    if (k < ncand) {
+      idx = candList[k];
       const int q = div_magic(idx, mIw), y = 3 + q, x = 3 + idx - q * iw;
       const int s = score[y][x];
       if (s > 0) {
@@ -306,61 +311,38 @@ __global__ __launch_bounds__(256) void k_fast_cells(Bufs b, FrameGeom g, int ini
               m1          = max(m1, t >= iniTh ? t : 0);
             }
         f1 = (s >= iniTh && s > m1);
-        f2 = (s > m2);
+        f2 = (s >= minTh && s > m2);
       }
     }
-    const unsigned long long b1 = __ballot(f1), b2 = __ballot(f2);
-    if (lane == 0) {
-      wavePre[0][it][wave] = __popcll(b1);
-      wavePre[1][it][wave] = __popcll(b2);
+    const unsigned long long bal = __ballot(f1 || f2), b1 = __ballot(f1), b2 = __ballot(f2);
+    int                      base = 0;
+    if (lane == 0 && bal) {
+      base = atomicAdd(&kpCount, __popcll(bal));
+      if (b1) atomicAdd(&cnt1, __popcll(b1));
+      if (b2) atomicAdd(&cnt2, __popcll(b2));
     }
+    base = __shfl(base, 0, 64);
+    if (f1 || f2) kpList[base + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)(idx | (f1 ? 0x8000 : 0) | (f2 ? 0x4000 : 0));
   }
   __syncthreads();
-  if (tid == 0) {
-    int tot1 = 0;
-    for (int it = 0; it < niter; it++)
-      for (int w = 0; w < 4; w++) tot1 += wavePre[0][it][w];
-    const int sel = tot1 > 0 ? 0 : 1;  // vKeysCell.empty() -> retry with minThFAST (:810-839)
-    int       run = 0;
-    for (int it = 0; it < niter; it++)
-      for (int w = 0; w < 4; w++) {
-        const int c         = wavePre[sel][it][w];
-        wavePre[sel][it][w] = run;
-        run += c;
-      }
-    selTh  = sel;
-    selTot = run;
-    *cntOut = run;
-  }
-  __syncthreads();
-  if (selTot == 0) return;
-  const int sel = selTh;
-  const int thr = sel == 0 ? iniTh : minTh;
+  // vKeysCell.empty() at iniThFAST -> retry with minThFAST (:810-839)
+  const int      nk   = kpCount;
+  const unsigned selB = cnt1 > 0 ? 0x8000u : 0x4000u;
+  // Pass 4 -- row-major emission order (cv::FAST's): rank of every selected keypoint = number of selected keypoints
+  // with a smaller pixel index.  The list is short (a few to a few dozen entries per cell).
   uint32_t* out = b.slots + (long long)f * g.totalSlots + L.slotBase + b.cellSlot[cell];
-  for (int it = 0; it < niter; it++) {
-    const int idx  = it * 256 + tid;
-    bool      flag = false;
-    int       x = 0, y = 0, s = 0;
-    if (idx < npix) {
-      { const int q = div_magic(idx, mIw); y = 3 + q, x = 3 + idx - q * iw; }
-      s = score[y][x];
-      if (s >= thr) {
-        int m = 0;
-#pragma unroll
-        for (int dy = -1; dy <= 1; dy++)
-#pragma unroll
-          for (int dx = -1; dx <= 1; dx++)
-            if (dx | dy) {
-              const int t = score[y + dy][x + dx];
-              m           = max(m, t >= thr ? t : 0);
-            }
-        flag = s > m;
+  if (tid == 0) *cntOut = cnt1 > 0 ? cnt1 : cnt2;
+  for (int e = tid; e < nk; e += 256) {
+    const unsigned me = kpList[e];
+    if (me & selB) {
+      const int idx = me & 0x3fff;
+      int       rank = 0;
+      for (int o = 0; o < nk; o++) {
+        const unsigned ot = kpList[o];
+        rank += ((ot & selB) && (int)(ot & 0x3fff) < idx) ? 1 : 0;
       }
-    }
-    const unsigned long long bal = __ballot(flag);
-    if (flag) {
-      const int pos = wavePre[sel][it][wave] + __popcll(bal & ((1ull << lane) - 1ull));
-      out[pos]      = (uint32_t)(x + ci_j * L.wCell) | ((uint32_t)(y + ci_i * L.hCell) << 12) | ((uint32_t)s << 24);
+      const int q = div_magic(idx, mIw), y = 3 + q, x = 3 + idx - q * iw;
+      out[rank]   = (uint32_t)(x + ci_j * L.wCell) | ((uint32_t)(y + ci_i * L.hCell) << 12) | ((uint32_t)score[y][x] << 24);
     }
   }
 }
@@ -369,7 +351,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(Bufs b, FrameGeom g, int ini
 // DistributeOctTree: one workgroup per (frame, level).  First gathers the per-cell candidate slots into
 // the feed order of the reference (cells row-major, row-major inside a cell), then runs octree_core.h.
 // ------------------------------------------------------------------------------------------------
-constexpr int kOctThreads  = 512;
+constexpr int kOctThreads  = 256;  // 124 VGPRs -> 4 waves/SIMD: 256-thread workgroups keep 4 (not 2) resident per CU
 constexpr int kOctLdsSort  = 2048;
 
 __device__ __forceinline__ void octree_args(const Bufs& b, const FrameGeom& g, int f, int level, OtArgs* a) {
