@@ -317,8 +317,11 @@ int orbx_extractor::run(const uint8_t* d_imgs, int B, int rows, int cols, size_t
   if (prof) HIP_TRY(hipEventRecord(evBlur1, stream2));
   HIP_TRY(hipEventRecord(evJoin, stream2));
   if (prof) HIP_TRY(hipEventRecord(ev[1], s));
-  hipLaunchKernelGGL(k_fast_cells, dim3(fastGrid, B), dim3(256), 0, s, b, g, std::min(std::max(iniTh, 0), 255),
-                     std::min(std::max(minTh, 0), 255));
+  {
+    const int per = fastGrid / 8;  // order-table slots per XCD
+    hipLaunchKernelGGL(k_fast_cells, dim3(8 * ((per + kFastCellsPerBlock - 1) / kFastCellsPerBlock), B), dim3(256), 0, s, b, g,
+                       std::min(std::max(iniTh, 0), 255), std::min(std::max(minTh, 0), 255), fastGrid);
+  }
   if (prof) HIP_TRY(hipEventRecord(ev[2], s));
   hipLaunchKernelGGL(k_octree, dim3(g.nlevels, B), dim3(kOctThreads), 0, s, b, g);
   if (prof) HIP_TRY(hipEventRecord(ev[3], s));

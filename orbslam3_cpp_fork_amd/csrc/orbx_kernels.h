@@ -196,154 +196,208 @@ __device__ __forceinline__ int fast_score(const uint8_t (*tile)[kFastTileMax], i
   return max(A, -Bm) - 1;
 }
 
-__global__ __launch_bounds__(256) void k_fast_cells(Bufs b, FrameGeom g, int iniTh, int minTh) {
+// Workgroup barrier that waits for this wave's LDS traffic only.  __syncthreads() also drains vmcnt, which would
+// stall every wave on the next cell's prefetch loads at the first barrier after they were issued.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+constexpr int kFastCellsPerBlock = 4;  // cells walked by one (persistent) workgroup
+constexpr int kFastPrefetch      = 7;  // tile dwords a thread may hold in flight: ceil(20 * 77 / 256)
+
+struct FastCell {
+  bool           valid;  // false: padding slot or a cell the reference skips (:782-793) / that has no interior
+  int            cell, level, ci_i, ci_j, tw, th, iw, ih, pitch, n4, tw4;
+  unsigned       mT4;
+  bool           al4;
+  const uint8_t* img;
+};
+
+__device__ __forceinline__ FastCell fast_decode(const Bufs& b, const FrameGeom& g, int slot, int nslots, int f) {
+  FastCell c;
+  c.valid = false;
+  c.cell  = slot < nslots ? b.cellOrder[slot] : -1;
+  if (c.cell < 0) return c;
+  int level = 0;
+  while (level + 1 < g.nlevels && c.cell >= g.lv[level + 1].cellBase) level++;
+  const LevelGeom& L  = g.lv[level];
+  const int        ci = c.cell - L.cellBase;
+  c.level = level;
+  c.ci_i = ci / L.nCols, c.ci_j = ci - c.ci_i * L.nCols;
+  const int iniY = kMinBorder + c.ci_i * L.hCell, iniX = kMinBorder + c.ci_j * L.wCell;
+  c.tw = c.th = c.iw = c.ih = 0;
+  if (iniY >= L.maxBY - 3 || iniX >= L.maxBX - 6) return c;  // skip rules (:782-793); count stays 0
+  const int maxY = min(iniY + L.hCell + 6, L.maxBY), maxX = min(iniX + L.wCell + 6, L.maxBX);
+  c.tw = maxX - iniX, c.th = maxY - iniY;
+  c.iw = c.tw - 6, c.ih = c.th - 6;  // interior scored by cv::FAST
+  if (c.iw <= 0 || c.ih <= 0) return c;
+  c.img = level_raw(b, g, level, f, &c.pitch) + (long long)iniY * c.pitch + iniX;
+  c.tw4 = (c.tw + 3) >> 2;
+  c.n4  = c.tw4 * c.th;
+  c.mT4 = 0xffffffffu / (unsigned)c.tw4 + 1u;
+  c.al4 = ((c.pitch & 3) == 0) && ((reinterpret_cast<uintptr_t>(c.img) & 3) == 0);
+  c.valid = true;
+  return c;
+}
+
+// issue the global loads of a cell's tile: 4 pixels per thread-slot where rows are 4-byte aligned, bytes otherwise
+__device__ __forceinline__ void fast_prefetch(const FastCell& c, int tid, uint32_t (&r)[kFastPrefetch]) {
+  if (!c.valid) return;
+#pragma unroll
+  for (int k = 0; k < kFastPrefetch; k++) {
+    const int idx = tid + k * 256;
+    if (idx < c.n4) {
+      const int      y = div_magic(idx, c.mT4), x = (idx - y * c.tw4) * 4;
+      const uint8_t* src = c.img + (long long)y * c.pitch + x;
+      uint32_t       v;
+      if (c.al4 && x + 4 <= c.tw) {
+        v = *reinterpret_cast<const uint32_t*>(src);
+      } else {
+        v = src[0];
+        if (x + 1 < c.tw) v |= (uint32_t)src[1] << 8;
+        if (x + 2 < c.tw) v |= (uint32_t)src[2] << 16;
+        if (x + 3 < c.tw) v |= (uint32_t)src[3] << 24;
+      }
+      r[k] = v;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_fast_cells(Bufs b, FrameGeom g, int iniTh, int minTh, int nslots) {
   constexpr int                     kMaxInt = (kFastTileMax - 6) * (kFastTileMax - 6);  // interior pixels of the largest tile
-  __shared__ __align__(16) uint8_t  tile[kFastTileMax][kFastTileMax];   // pixels; after scoring: NMS flag bits
+  __shared__ __align__(16) uint8_t  tile[kFastTileMax][kFastTileMax];   // pixels
   __shared__ __align__(16) uint8_t  score[kFastTileMax][kFastTileMax];  // corner score (0 = not a corner at lowTh)
   __shared__ unsigned short         candList[kMaxInt];                  // pass-1 survivors (pixel index in the interior)
   __shared__ unsigned short         kpList[kMaxInt / 2 + 64];           // NMS survivors under either threshold
   __shared__ int                    candCount, kpCount, cnt1, cnt2;
-  // block -> cell through a host-built order table: whole cell ROWS are dealt to the 8 XCDs (balanced by cell count),
-  // so that horizontally adjacent cells (which share 128-B lines and the 6-px overlap) sit behind one L2.  -1 = padding.
-  const int cell = b.cellOrder[blockIdx.x], f = blockIdx.y, tid = threadIdx.x;
-  if (cell < 0) return;
-  int level = 0;
-  while (level + 1 < g.nlevels && cell >= g.lv[level + 1].cellBase) level++;
-  const LevelGeom& L  = g.lv[level];
-  const int        ci = cell - L.cellBase;
-  const int        ci_i = ci / L.nCols, ci_j = ci - ci_i * L.nCols;
-  int*             cntOut = b.cellCount + (long long)f * g.totalCells + cell;
-  const int        iniY = kMinBorder + ci_i * L.hCell, iniX = kMinBorder + ci_j * L.wCell;
-  if (iniY >= L.maxBY - 3 || iniX >= L.maxBX - 6) {  // skip rules (:782-793)
-    if (tid == 0) *cntOut = 0;
-    return;
-  }
-  const int maxY = min(iniY + L.hCell + 6, L.maxBY), maxX = min(iniX + L.wCell + 6, L.maxBX);
-  const int tw = maxX - iniX, th = maxY - iniY;
-  const int iw = tw - 6, ih = th - 6;  // interior scored by cv::FAST
-  if (iw <= 0 || ih <= 0) {
-    if (tid == 0) *cntOut = 0;
-    return;
-  }
-  int            pitch;
-  const uint8_t* img = level_raw(b, g, level, f, &pitch) + (long long)iniY * pitch + iniX;
-  const unsigned mIw = iw == 1 ? 0u : 0xffffffffu / (unsigned)iw + 1u;  // interior-width divider for idx -> (row, col)
-  {
-    // tile load: 4 pixels per thread where the row is 4-byte aligned in memory, bytes otherwise
-    const int      tw4 = (tw + 3) >> 2;
-    const unsigned mT4 = 0xffffffffu / (unsigned)tw4 + 1u;
-    const bool     al4 = ((pitch & 3) == 0) && ((reinterpret_cast<uintptr_t>(img) & 3) == 0);
-    for (int idx = tid; idx < tw4 * th; idx += 256) {
-      const int      y = div_magic(idx, mT4), x = (idx - y * tw4) * 4;
-      const uint8_t* src = img + (long long)y * pitch + x;
-      uint32_t       v;
-      if (al4 && x + 4 <= tw) {
-        v = *reinterpret_cast<const uint32_t*>(src);
-      } else {
-        v = src[0];
-        if (x + 1 < tw) v |= (uint32_t)src[1] << 8;
-        if (x + 2 < tw) v |= (uint32_t)src[2] << 16;
-        if (x + 3 < tw) v |= (uint32_t)src[3] << 24;
+  // Workgroup b walks kFastCellsPerBlock consecutive slots of XCD (b % 8)'s list in the host-built order table
+  // (whole cell ROWS dealt to the 8 XCDs, balanced by cell count: horizontally adjacent cells share 128-B lines and
+  // the 6-px overlap, so they sit behind one L2).  While a cell is processed the NEXT cell's tile is already in
+  // flight into registers, which hides the global-load latency that otherwise parks every wave at cell start.
+  const int f = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+  const int xcd = blockIdx.x & 7, k0 = (blockIdx.x >> 3) * kFastCellsPerBlock;
+  const int lowTh = max(min(iniTh, minTh), 1);
+  uint32_t  pre[kFastPrefetch];
+  FastCell  cur = fast_decode(b, g, k0 * 8 + xcd, nslots, f);
+  fast_prefetch(cur, tid, pre);
+  for (int cc = 0; cc < kFastCellsPerBlock; cc++) {
+    FastCell nxt;
+    nxt.valid = false, nxt.cell = -1;
+    if (cc + 1 < kFastCellsPerBlock) nxt = fast_decode(b, g, (k0 + cc + 1) * 8 + xcd, nslots, f);
+    if (!cur.valid) {
+      if (cur.cell >= 0 && tid == 0) b.cellCount[(long long)f * g.totalCells + cur.cell] = 0;
+      cur = nxt;
+      fast_prefetch(cur, tid, pre);
+      continue;
+    }
+    const LevelGeom& L  = g.lv[cur.level];
+    const int        iw = cur.iw, ih = cur.ih;
+    const unsigned   mIw = iw == 1 ? 0u : 0xffffffffu / (unsigned)iw + 1u;  // interior-width divider for idx -> (row, col)
+    // registers -> LDS (kFastTileMax is a multiple of 4: aligned; spill past tw stays inside the row)
+#pragma unroll
+    for (int k = 0; k < kFastPrefetch; k++) {
+      const int idx = tid + k * 256;
+      if (idx < cur.n4) {
+        const int y = div_magic(idx, cur.mT4), x = (idx - y * cur.tw4) * 4;
+        *reinterpret_cast<uint32_t*>(&tile[y][x])  = pre[k];
+        *reinterpret_cast<uint32_t*>(&score[y][x]) = 0;
       }
-      *reinterpret_cast<uint32_t*>(&tile[y][x])  = v;  // kFastTileMax is a multiple of 4: aligned; spill past tw stays inside the row
-      *reinterpret_cast<uint32_t*>(&score[y][x]) = 0;
     }
     if (tid == 0) candCount = 0, kpCount = 0, cnt1 = 0, cnt2 = 0;
-  }
-  __syncthreads();
-  const int npix  = iw * ih;
-  const int lowTh = max(min(iniTh, minTh), 1);
-  const int lane  = tid & 63;
-  // Pass 1 -- necessary condition + compaction.  A 9-arc of the 16-pixel circle always contains 4 CONSECUTIVE even
-  // circle positions (0, 2, .., 14), so a pixel can only score >= lowTh if four consecutive even positions are all
-  // darker than v - lowTh or all brighter than v + lowTh.  Survivors go (any order) to an LDS list so that the
-  // full score below runs with all lanes busy.
-  for (int idx = tid; idx < ((npix + 63) & ~63); idx += 256) {
-    bool keep = false;
-    if (idx < npix) {
-      const int q = div_magic(idx, mIw), y = 3 + q, x = 3 + idx - q * iw;
-      const int v = tile[y][x];
-      const int lo = v - lowTh, hi = v + lowTh;
-      const int p0 = tile[y + 3][x], p2 = tile[y + 2][x + 2], p4 = tile[y][x + 3], p6 = tile[y - 2][x + 2];
-      const int p8 = tile[y - 3][x], p10 = tile[y - 2][x - 2], p12 = tile[y][x - 3], p14 = tile[y + 2][x - 2];
-      unsigned dk = (p0 < lo) | ((p2 < lo) << 1) | ((p4 < lo) << 2) | ((p6 < lo) << 3) | ((p8 < lo) << 4) | ((p10 < lo) << 5) |
-                    ((p12 < lo) << 6) | ((p14 < lo) << 7);
-      unsigned br = (p0 > hi) | ((p2 > hi) << 1) | ((p4 > hi) << 2) | ((p6 > hi) << 3) | ((p8 > hi) << 4) | ((p10 > hi) << 5) |
-                    ((p12 > hi) << 6) | ((p14 > hi) << 7);
-      dk |= dk << 8, br |= br << 8;  // cyclic
-      dk &= dk >> 1, dk &= dk >> 2;  // bit i = positions i..i+3 all set
-      br &= br >> 1, br &= br >> 2;
-      keep = ((dk | br) & 0xffu) != 0;
+    __syncthreads();
+    fast_prefetch(nxt, tid, pre);  // in flight during the four passes below
+    const int npix = iw * ih;
+    // Pass 1 -- necessary condition + compaction.  A 9-arc of the 16-pixel circle always contains 4 CONSECUTIVE even
+    // circle positions (0, 2, .., 14), so a pixel can only score >= lowTh if four consecutive even positions are all
+    // darker than v - lowTh or all brighter than v + lowTh.  Survivors go (any order) to an LDS list so that the
+    // full score below runs with all lanes busy.
+    for (int idx = tid; idx < ((npix + 63) & ~63); idx += 256) {
+      bool keep = false;
+      if (idx < npix) {
+        const int q = div_magic(idx, mIw), y = 3 + q, x = 3 + idx - q * iw;
+        const int v = tile[y][x];
+        const int lo = v - lowTh, hi = v + lowTh;
+        const int p0 = tile[y + 3][x], p2 = tile[y + 2][x + 2], p4 = tile[y][x + 3], p6 = tile[y - 2][x + 2];
+        const int p8 = tile[y - 3][x], p10 = tile[y - 2][x - 2], p12 = tile[y][x - 3], p14 = tile[y + 2][x - 2];
+        unsigned dk = (p0 < lo) | ((p2 < lo) << 1) | ((p4 < lo) << 2) | ((p6 < lo) << 3) | ((p8 < lo) << 4) | ((p10 < lo) << 5) |
+                      ((p12 < lo) << 6) | ((p14 < lo) << 7);
+        unsigned br = (p0 > hi) | ((p2 > hi) << 1) | ((p4 > hi) << 2) | ((p6 > hi) << 3) | ((p8 > hi) << 4) | ((p10 > hi) << 5) |
+                      ((p12 > hi) << 6) | ((p14 > hi) << 7);
+        dk |= dk << 8, br |= br << 8;  // cyclic
+        dk &= dk >> 1, dk &= dk >> 2;  // bit i = positions i..i+3 all set
+        br &= br >> 1, br &= br >> 2;
+        keep = ((dk | br) & 0xffu) != 0;
+      }
+      const unsigned long long bal = __ballot(keep);
+      int                      base = 0;
+      if (lane == 0 && bal) base = atomicAdd(&candCount, __popcll(bal));
+      base = __shfl(base, 0, 64);
+      if (keep) candList[base + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)idx;
     }
-    const unsigned long long bal = __ballot(keep);
-    int                      base = 0;
-    if (lane == 0 && bal) base = atomicAdd(&candCount, __popcll(bal));
-    base = __shfl(base, 0, 64);
-    if (keep) candList[base + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)idx;
-  }
-  __syncthreads();
-  // Pass 2 -- full corner score of the survivors
-  const int ncand = candCount;
-  for (int k = tid; k < ncand; k += 256) {
-    const int idx = candList[k];
-    const int q = div_magic(idx, mIw), y = 3 + q, x = 3 + idx - q * iw;
-    const int s = fast_score(tile, x, y);
-    score[y][x] = (uint8_t)(s >= lowTh ? s : 0);  // scores below both thresholds are never corners
-  }
-  __syncthreads();
-  // Pass 3 -- strict 3x3 NMS under both thresholds, over the survivors only.  Flags go to a sparse list.
-  for (int k = tid; k < ((ncand + 63) & ~63); k += 256) {
-    bool f1 = false, f2 = false;
-    int  idx = 0;
-    if (k < ncand) {
-      idx = candList[k];
+    lds_barrier();
+    // Pass 2 -- full corner score of the survivors
+    const int ncand = candCount;
+    for (int k = tid; k < ncand; k += 256) {
+      const int idx = candList[k];
       const int q = div_magic(idx, mIw), y = 3 + q, x = 3 + idx - q * iw;
-      const int s = score[y][x];
-      if (s > 0) {
-        int m1 = 0, m2 = 0;  // max neighbour score under each threshold
+      const int s = fast_score(tile, x, y);
+      score[y][x] = (uint8_t)(s >= lowTh ? s : 0);  // scores below both thresholds are never corners
+    }
+    lds_barrier();
+    // Pass 3 -- strict 3x3 NMS under both thresholds, over the survivors only.  Flags go to a sparse list.
+    for (int k = tid; k < ((ncand + 63) & ~63); k += 256) {
+      bool f1 = false, f2 = false;
+      int  idx = 0;
+      if (k < ncand) {
+        idx = candList[k];
+        const int q = div_magic(idx, mIw), y = 3 + q, x = 3 + idx - q * iw;
+        const int s = score[y][x];
+        if (s > 0) {
+          int m1 = 0, m2 = 0;  // max neighbour score under each threshold
 #pragma unroll
-        for (int dy = -1; dy <= 1; dy++)
+          for (int dy = -1; dy <= 1; dy++)
 #pragma unroll
-          for (int dx = -1; dx <= 1; dx++)
-            if (dx | dy) {
-              const int t = score[y + dy][x + dx];
-              m2          = max(m2, t);
-              m1          = max(m1, t >= iniTh ? t : 0);
-            }
-        f1 = (s >= iniTh && s > m1);
-        f2 = (s >= minTh && s > m2);
+            for (int dx = -1; dx <= 1; dx++)
+              if (dx | dy) {
+                const int t = score[y + dy][x + dx];
+                m2          = max(m2, t);
+                m1          = max(m1, t >= iniTh ? t : 0);
+              }
+          f1 = (s >= iniTh && s > m1);
+          f2 = (s >= minTh && s > m2);
+        }
+      }
+      const unsigned long long bal = __ballot(f1 || f2), b1 = __ballot(f1), b2 = __ballot(f2);
+      int                      base = 0;
+      if (lane == 0 && bal) {
+        base = atomicAdd(&kpCount, __popcll(bal));
+        if (b1) atomicAdd(&cnt1, __popcll(b1));
+        if (b2) atomicAdd(&cnt2, __popcll(b2));
+      }
+      base = __shfl(base, 0, 64);
+      if (f1 || f2) kpList[base + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)(idx | (f1 ? 0x8000 : 0) | (f2 ? 0x4000 : 0));
+    }
+    lds_barrier();
+    // vKeysCell.empty() at iniThFAST -> retry with minThFAST (:810-839)
+    const int      nk   = kpCount;
+    const unsigned selB = cnt1 > 0 ? 0x8000u : 0x4000u;
+    // Pass 4 -- row-major emission order (cv::FAST's): rank of every selected keypoint = number of selected keypoints
+    // with a smaller pixel index.  The list is short (a few to a few dozen entries per cell).
+    uint32_t* out = b.slots + (long long)f * g.totalSlots + L.slotBase + b.cellSlot[cur.cell];
+    if (tid == 0) b.cellCount[(long long)f * g.totalCells + cur.cell] = cnt1 > 0 ? cnt1 : cnt2;
+    for (int e = tid; e < nk; e += 256) {
+      const unsigned me = kpList[e];
+      if (me & selB) {
+        const int idx = me & 0x3fff;
+        int       rank = 0;
+        for (int o = 0; o < nk; o++) {
+          const unsigned ot = kpList[o];
+          rank += ((ot & selB) && (int)(ot & 0x3fff) < idx) ? 1 : 0;
+        }
+        const int q = div_magic(idx, mIw), y = 3 + q, x = 3 + idx - q * iw;
+        out[rank]   = (uint32_t)(x + cur.ci_j * L.wCell) | ((uint32_t)(y + cur.ci_i * L.hCell) << 12) | ((uint32_t)score[y][x] << 24);
       }
     }
-    const unsigned long long bal = __ballot(f1 || f2), b1 = __ballot(f1), b2 = __ballot(f2);
-    int                      base = 0;
-    if (lane == 0 && bal) {
-      base = atomicAdd(&kpCount, __popcll(bal));
-      if (b1) atomicAdd(&cnt1, __popcll(b1));
-      if (b2) atomicAdd(&cnt2, __popcll(b2));
-    }
-    base = __shfl(base, 0, 64);
-    if (f1 || f2) kpList[base + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)(idx | (f1 ? 0x8000 : 0) | (f2 ? 0x4000 : 0));
-  }
-  __syncthreads();
-  // vKeysCell.empty() at iniThFAST -> retry with minThFAST (:810-839)
-  const int      nk   = kpCount;
-  const unsigned selB = cnt1 > 0 ? 0x8000u : 0x4000u;
-  // Pass 4 -- row-major emission order (cv::FAST's): rank of every selected keypoint = number of selected keypoints
-  // with a smaller pixel index.  The list is short (a few to a few dozen entries per cell).
-  uint32_t* out = b.slots + (long long)f * g.totalSlots + L.slotBase + b.cellSlot[cell];
-  if (tid == 0) *cntOut = cnt1 > 0 ? cnt1 : cnt2;
-  for (int e = tid; e < nk; e += 256) {
-    const unsigned me = kpList[e];
-    if (me & selB) {
-      const int idx = me & 0x3fff;
-      int       rank = 0;
-      for (int o = 0; o < nk; o++) {
-        const unsigned ot = kpList[o];
-        rank += ((ot & selB) && (int)(ot & 0x3fff) < idx) ? 1 : 0;
-      }
-      const int q = div_magic(idx, mIw), y = 3 + q, x = 3 + idx - q * iw;
-      out[rank]   = (uint32_t)(x + ci_j * L.wCell) | ((uint32_t)(y + ci_i * L.hCell) << 12) | ((uint32_t)score[y][x] << 24);
-    }
+    lds_barrier();  // tile / score / lists are rewritten by the next cell
+    cur = nxt;
   }
 }
 
