@@ -90,6 +90,7 @@ def main():
     ap.add_argument("--workload", default="vga_stream_640x480_8lvl_1000feat_extract+match", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-match", action="store_true", help="extract only")
+    ap.add_argument("--lanes", type=int, default=1, help="chunks in flight (each on its own HIP stream and handles)")
     args = ap.parse_args()
 
     import torch
@@ -116,61 +117,91 @@ def main():
     frames_np = synth.make_stream(rows, cols, B, camera_idx=shard.camera_of_rank(rank, world))
     d_imgs = torch.from_numpy(frames_np).to(dev)
 
-    ex = ORBextractor(nfeat, 1.2, 8, 20, 7, device=local_rank)
-    mt = ORBmatcher(0.7, True, device=local_rank)
-    cap = ex.max_keypoints(rows, cols)
-    d_kps = torch.zeros((B, cap, 7), dtype=torch.float32, device=dev)
-    d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
-    d_cnt = torch.zeros((B, 2), dtype=torch.int32, device=dev)
+    cap = None
     pairs = np.stack([(np.arange(B) - 1) % B, np.arange(B)], 1).astype(np.int32)  # frame f-1 (query) vs frame f (train)
     d_pairs = torch.from_numpy(pairs).to(dev)
-    d_match = torch.full((B, cap), -1, dtype=torch.int32, device=dev)
-    d_nm = torch.zeros(B, dtype=torch.int32, device=dev)
-    # one explicit (non-default) HIP stream carries the whole step: extractor kernels, matcher kernels, gather packing
-    tstream = torch.cuda.Stream(device=dev)
-    torch.cuda.set_stream(tstream)
-    stream = tstream.cuda_stream
-    assert stream, "need a non-null stream handle (NULL selects the handle's private stream in the C ABI)"
-    gather = shard.RecordGather(B, cap, dev, world, rank) if world > 1 else None
 
-    # HIP events on the launch stream (torch's current stream IS the stream handed to the C ABI) around the matcher
-    # launches; the extractor records its own per-stage events internally (orbx_set_profiling).
-    match_ev = []
+    class Lane:
+        """One in-flight chunk: its own extractor / matcher handles, output buffers and HIP stream.  Consecutive steps
+        alternate between the lanes, so chunk i+1's throughput-bound kernels run beside chunk i's latency-bound ones
+        (quadtree, descriptor gathers, claim resolution), exactly as a double-buffered camera stream would."""
 
-    def step(timed=False):
-        ex.extract_batch_device(d_imgs, B, rows, cols, cols, rows * cols, d_kps, d_desc, d_cnt, cap, (0, 1000), stream=stream)
-        if not args.no_match:
-            if timed:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-            mt.match_pairs_device(d_desc, d_kps, d_cnt, cap, d_pairs, B, d_match, d_nm, stream=stream)
-            if timed:
-                e1.record()
-                match_ev.append((e0, e1))
-        if gather is not None:
-            gather(d_kps, d_desc, d_cnt)
+        def __init__(self):
+            self.ex = ORBextractor(nfeat, 1.2, 8, 20, 7, device=local_rank)
+            self.mt = ORBmatcher(0.7, True, device=local_rank)
+            self.cap = self.ex.max_keypoints(rows, cols)
+            self.d_kps = torch.zeros((B, self.cap, 7), dtype=torch.float32, device=dev)
+            self.d_desc = torch.zeros((B, self.cap, 32), dtype=torch.uint8, device=dev)
+            self.d_cnt = torch.zeros((B, 2), dtype=torch.int32, device=dev)
+            self.d_match = torch.full((B, self.cap), -1, dtype=torch.int32, device=dev)
+            self.d_nm = torch.zeros(B, dtype=torch.int32, device=dev)
+            self.tstream = torch.cuda.Stream(device=dev)  # explicit, non-default: NULL would select the handle's private stream
+            self.stream = self.tstream.cuda_stream
+            assert self.stream
+            self.gather = shard.RecordGather(B, self.cap, dev, world, rank) if world > 1 else None
+            self.pending = None
+            self.match_ev = []
+
+        def step(self, timed=False):
+            with torch.cuda.stream(self.tstream):
+                if self.pending is not None:  # the previous gather of this lane must have drained its send buffer
+                    self.pending.wait()
+                    self.pending = None
+                self.ex.extract_batch_device(d_imgs, B, rows, cols, cols, rows * cols, self.d_kps, self.d_desc, self.d_cnt, self.cap, (0, 1000), stream=self.stream)
+                if not args.no_match:
+                    if timed:
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                    self.mt.match_pairs_device(self.d_desc, self.d_kps, self.d_cnt, self.cap, d_pairs, B, self.d_match, self.d_nm, stream=self.stream)
+                    if timed:
+                        e1.record()
+                        self.match_ev.append((e0, e1))
+                if self.gather is not None:
+                    # asynchronous RCCL gather on the collective's own stream: overlaps the next chunk's extraction
+                    self.pending = self.gather(self.d_kps, self.d_desc, self.d_cnt, async_op=True)
+
+        def drain(self):
+            if self.pending is not None:
+                with torch.cuda.stream(self.tstream):
+                    self.pending.wait()
+                self.pending = None
+
+    lanes = [Lane() for _ in range(max(1, args.lanes))]
+    cap = lanes[0].cap
 
     def fence():
+        for ln in lanes:
+            ln.drain()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    for i in range(args.warmup):
+        lanes[i % len(lanes)].step()
     fence()
-    ex.set_profiling(True)
+    for ln in lanes:
+        ln.ex.set_profiling(True)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(timed=True)
+    for i in range(args.steps):
+        lanes[i % len(lanes)].step(timed=True)
     fence()
     dt = time.perf_counter() - t0
-    stage = ex.stage_ms()
-    stage["match"] = float(np.mean([a.elapsed_time(b) for a, b in match_ev])) if match_ev else 0.0
-    ex.set_profiling(False)
+    stages = []
+    for ln in lanes:
+        try:
+            stages.append(ln.ex.stage_ms())
+        except Exception:  # a lane that ran no timed step has nothing recorded
+            pass
+    stage = {k: float(np.mean([st[k] for st in stages])) for k in stages[0]}
+    mev = [a.elapsed_time(b) for ln in lanes for a, b in ln.match_ev]
+    stage["match"] = float(np.mean(mev)) if mev else 0.0
+    for ln in lanes:
+        ln.ex.set_profiling(False)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    d_cnt, d_nm = lanes[0].d_cnt, lanes[0].d_nm
 
     total_frames = B * args.steps * world
     value = total_frames / dt
@@ -179,9 +210,12 @@ def main():
 
     if rank == 0:
         ab = algorithmic_bytes(rows, cols, nfeat)
-        # dominant kernel class = the stage with the largest mean HIP-event duration in the timed region
-        kernels = {"pyramid": "k_resize_level", "fast": "k_fast_cells", "octree": "k_octree", "orient_describe": "k_orient_describe",
+        # dominant kernel class = the stage with the largest mean HIP-event duration in the timed region.  The blur runs
+        # on a side stream concurrently with FAST (blur_wait ~ 0 means fully inside the FAST..layout interval), so the
+        # "fast" stage is priced as the concurrent pair: algorithmic bytes of both, wall interval of the stage.
+        kernels = {"pyramid": "k_resize_level", "fast": "k_fast_cells||k_blur_levels", "octree": "k_octree", "orient_describe": "k_orient_describe",
                    "match": "k_group_topk+k_group_resolve"}
+        ab["fast"] = ab["fast"] + ab["blur"]
         # matcher: descriptors of both frames read once + one match index per query ((nq + nt) * 32 + nq * 4)
         ab["match"] = int(2 * cnt[:, 0].mean() * 32 + cnt[:, 0].mean() * 4)
         dom = max(kernels, key=lambda k: stage[k])
@@ -189,6 +223,16 @@ def main():
         # only the keypoint records (quadtree) or gather through L2 (orientation/BRIEF): price those by the output term.
         per_frame = ab.get(dom, ab["output"])
         achieved = per_frame * B / (stage[dom] * 1e-3) / 1e9
+        # HBM traffic of that kernel from the committed PMC passes of the same command (FETCH_SIZE x gfx950 correction +
+        # WRITE_SIZE, collected by tools/collect_profiles.sh; bench.py itself cannot read hardware counters)
+        traffic = None
+        try:
+            summ = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
+            if summ.get("bench", {}).get("config", {}).get("frames_per_step_per_gpu") == B and cols == summ["bench"]["config"]["cols"]:
+                names = kernels[dom].replace("||", "+").split("+")
+                traffic = int(sum(summ["kernels"][n]["hbm_traffic_MB_per_launch"] for n in names) * 1e6)
+        except Exception:
+            traffic = None
         out = {
             "metric": "frames/s ORB extract+match (640x480, 8 lvl, 1000 feat)" if cols == 640 else "frames/s ORB extract+match",
             "value": round(value, 2),
@@ -205,6 +249,7 @@ def main():
             "config": {
                 "workload": args.workload + ("" if not args.no_match else " [extract only]"),
                 "frames_per_step_per_gpu": B,
+                "chunks_in_flight": len(lanes),
                 "rows": rows,
                 "cols": cols,
                 "nfeatures": nfeat,
@@ -220,7 +265,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 6),
-                "traffic": None,
+                "traffic": traffic,
                 "algorithmic_bytes_per_launch": per_frame * B,
                 "avg_launch_ms": round(stage[dom], 5),
             },

@@ -49,12 +49,14 @@ class RecordGather:
         self.send[self._o2:].copy_(d_desc.reshape(-1))
         return self.send
 
-    def __call__(self, d_kps, d_desc, d_cnt):
+    def __call__(self, d_kps, d_desc, d_cnt, async_op=False):
+        """Pack on the current stream, then gather.  async_op=True returns the collective's work handle (call .wait()
+        on it before the send buffer is packed again); the result is in self.recv on rank `dst`."""
         import torch.distributed as dist
 
         self.pack(d_kps, d_desc, d_cnt)
-        dist.gather(self.send, self.recv, dst=self.dst)
-        return self.recv
+        work = dist.gather(self.send, self.recv, dst=self.dst, async_op=async_op)
+        return work if async_op else self.recv
 
     def unpack(self, buf):
         """buf: one rank's byte tensor (on any device) -> (counts[B,2] int32, kps[B,cap] KP_DTYPE, desc[B,cap,32])."""
