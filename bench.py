@@ -210,12 +210,9 @@ def main():
 
     if rank == 0:
         ab = algorithmic_bytes(rows, cols, nfeat)
-        # dominant kernel class = the stage with the largest mean HIP-event duration in the timed region.  The blur runs
-        # on a side stream concurrently with FAST (blur_wait ~ 0 means fully inside the FAST..layout interval), so the
-        # "fast" stage is priced as the concurrent pair: algorithmic bytes of both, wall interval of the stage.
-        kernels = {"pyramid": "k_resize_level", "fast": "k_fast_cells||k_blur_levels", "octree": "k_octree", "orient_describe": "k_orient_describe",
+        # dominant kernel class = the stage with the largest mean HIP-event duration in the timed region
+        kernels = {"pyramid": "k_resize_level", "fast": "k_fast_cells", "octree": "k_octree", "blur": "k_blur_levels", "orient_describe": "k_orient_describe",
                    "match": "k_group_topk+k_group_resolve"}
-        ab["fast"] = ab["fast"] + ab["blur"]
         # matcher: descriptors of both frames read once + one match index per query ((nq + nt) * 32 + nq * 4)
         ab["match"] = int(2 * cnt[:, 0].mean() * 32 + cnt[:, 0].mean() * 4)
         dom = max(kernels, key=lambda k: stage[k])

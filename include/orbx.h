@@ -75,8 +75,8 @@ int orbx_pyramid_level(orbx_t* h, int frame, int level, uint8_t* dst, size_t dst
 /* Stage timing with HIP events recorded on the launch stream between the kernels of every batch:
  * enable (resets the record), run batches, then read the mean milliseconds per stage over the batches
  * recorded since (at most the last 32); returns the number of batches averaged.  Stages: 0 pyramid
- * (all resize launches), 1 FAST, 2 quadtree, 3 layout, 4 wait for the blur (it runs on a side stream beside stages
- * 1-3; 0 when fully hidden), 5 orientation+descriptor, 6 whole batch. */
+ * (all resize launches), 1 FAST, 2 quadtree, 3 layout, 4 blur (with ORBX_OVERLAP_BLUR=1: the wait for the blur's
+ * side stream), 5 orientation+descriptor, 6 whole batch. */
 #define ORBX_NUM_STAGES 7
 void orbx_set_profiling(orbx_t* h, int enable);
 int  orbx_get_stage_ms(orbx_t* h, float* ms /* ORBX_NUM_STAGES */);

@@ -14,7 +14,7 @@ KP_DTYPE = np.dtype(
     [("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")]
 )
 NUM_STAGES = 7
-STAGE_NAMES = ("pyramid", "fast", "octree", "layout", "blur_wait", "orient_describe", "total")
+STAGE_NAMES = ("pyramid", "fast", "octree", "layout", "blur", "orient_describe", "total")
 
 _lib = None
 

@@ -540,62 +540,97 @@ __device__ __forceinline__ int reflect101(int p, int n) {
 // Work items are dealt level by level, 256 per workgroup (LevelGeom::blurTileBase counts workgroups).
 constexpr int kBlurRows = 16;
 
-__device__ __forceinline__ void blur_load10(const uint8_t* __restrict__ row, int x0, int w, bool fast, int (&p)[10]) {
-  if (fast) {
-    const uint32_t a = *reinterpret_cast<const uint32_t*>(row + x0 - 4);
-    const uint32_t m = *reinterpret_cast<const uint32_t*>(row + x0);
-    const uint32_t c = *reinterpret_cast<const uint32_t*>(row + x0 + 4);
-    p[0] = (a >> 8) & 0xff, p[1] = (a >> 16) & 0xff, p[2] = a >> 24;
-    p[3] = m & 0xff, p[4] = (m >> 8) & 0xff, p[5] = (m >> 16) & 0xff, p[6] = m >> 24;
-    p[7] = c & 0xff, p[8] = (c >> 8) & 0xff, p[9] = (c >> 16) & 0xff;
+// Three dwords covering columns x0-4 .. x0+7 of one row (reflect-101 at the image edges).
+__device__ __forceinline__ int reflect101_once(int p, int n) {  // valid for -n < p < 2n - 1
+  p = p < 0 ? -p : p;
+  return p >= n ? 2 * n - 2 - p : p;
+}
+
+template <bool FAST>
+__device__ __forceinline__ void blur_load12(const uint8_t* __restrict__ row, int x0, int w, uint32_t& a, uint32_t& m, uint32_t& c) {
+  if (FAST) {
+    a = *reinterpret_cast<const uint32_t*>(row + x0 - 4);
+    m = *reinterpret_cast<const uint32_t*>(row + x0);
+    c = *reinterpret_cast<const uint32_t*>(row + x0 + 4);
   } else {
+    a = m = c = 0;
 #pragma unroll
-    for (int i = 0; i < 10; i++) p[i] = row[reflect101(x0 - 3 + i, w)];
+    for (int i = 0; i < 4; i++) {
+      a |= (uint32_t)row[reflect101_once(x0 - 4 + i, w)] << (8 * i);
+      m |= (uint32_t)row[reflect101_once(x0 + i, w)] << (8 * i);
+      c |= (uint32_t)row[reflect101_once(x0 + 4 + i, w)] << (8 * i);
+    }
   }
 }
 
+// One 4-column x kBlurRows strip.  The 7-row window of horizontal sums is a ring indexed with compile-time
+// constants (the row loop is fully unrolled), so nothing is shifted.
+template <bool FAST>
+__device__ __forceinline__ void blur_strip(const uint8_t* __restrict__ src, int pitch, uint8_t* __restrict__ dst, int dpitch, int w, int h, int x0,
+                                           int y0) {
+  // Q8 taps {18,34,48,56,48,34,18} as two byte vectors for v_dot4_u32_u8: window bytes p[i..i+3] and p[i+4..i+6]
+  const uint32_t T0 = 18u | (34u << 8) | (48u << 16) | (56u << 24), T1 = 48u | (34u << 8) | (18u << 16);
+  uint32_t       hr[7][4];
+#pragma unroll
+  for (int r = 0; r < kBlurRows + 6; r++) {
+    int sy = y0 + r - 3;  // reflect-101 rows; beyond the image bottom the strip's extra rows are never used
+    sy     = sy < 0 ? -sy : sy;
+    sy     = sy >= h ? max(2 * h - 2 - sy, 0) : sy;
+    uint32_t a, m, c;
+    blur_load12<FAST>(src + (long long)sy * pitch, x0, w, a, m, c);
+    // horizontal pass: output column x0+i sees bytes (x0+i-3 .. x0+i+3); alignbyte slides the 12-byte window
+    uint32_t* hn = hr[r % 7];
+    hn[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(c, m, 1), T1, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(m, a, 1), T0, 0u, false), false);
+    hn[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(c, m, 2), T1, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(m, a, 2), T0, 0u, false), false);
+    hn[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(c, m, 3), T1, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(m, a, 3), T0, 0u, false), false);
+    hn[3] = __builtin_amdgcn_udot4(c, T1, __builtin_amdgcn_udot4(m, T0, 0u, false), false);
+    if (r >= 6) {
+      const int oy = y0 + r - 6;
+      if (oy < h) {
+        const uint32_t *h0 = hr[(r - 6) % 7], *h1 = hr[(r - 5) % 7], *h2 = hr[(r - 4) % 7], *h3 = hr[(r - 3) % 7], *h4 = hr[(r - 2) % 7],
+                       *h5 = hr[(r - 1) % 7], *h6 = hr[r % 7];
+        uint32_t out = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const uint32_t sacc = 18u * (h0[i] + h6[i]) + 34u * (h1[i] + h5[i]) + 48u * (h2[i] + h4[i]) + 56u * h3[i];
+          out |= ((sacc + 32768u) >> 16) << (8 * i);
+        }
+        *reinterpret_cast<uint32_t*>(dst + (long long)oy * dpitch + x0) = out;
+      }
+    }
+  }
+}
+
+// Work items of a level = (row strip, 4-column group).  Groups whose 12-byte window lies inside the row take the
+// aligned-dword path; the 2-3 edge groups of every strip need reflected byte loads.  Mixing them in one wave makes the
+// whole wave run the slow path, so the interior items are dealt first (dense waves, fast path only) and all edge
+// items of the level afterwards in workgroups of their own.  LevelGeom::blurTileBase counts workgroups.
 __global__ __launch_bounds__(256) void k_blur_levels(Bufs b, FrameGeom g) {
   const int f = blockIdx.y, tid = threadIdx.x;
   int       t = xcd_item(blockIdx.x, g.totalBlurTiles), level = 0;
   if (t < 0) return;
   while (level + 1 < g.nlevels && t >= g.lv[level + 1].blurTileBase) level++;
-  const LevelGeom& L      = g.lv[level];
-  const int        groups = (L.w + 3) >> 2;
-  const int        item   = (t - L.blurTileBase) * 256 + tid;
-  const int        strip  = item / groups;
-  const int        x0     = (item - strip * groups) * 4;
-  const int        y0     = strip * kBlurRows;
-  if (y0 >= L.h) return;
+  const LevelGeom& L = g.lv[level];
+  t -= L.blurTileBase;
   int            pitch;
   const uint8_t* src = level_raw(b, g, level, f, &pitch);
   uint8_t*       dst = b.blur + (long long)f * g.blurBytes + L.blurOff;
-  // aligned 32-bit loads need a 4-byte aligned row base; columns x0-4 .. x0+7 must lie inside the row
-  const bool fast = x0 >= 4 && x0 + 8 <= L.w && ((pitch & 3) == 0) && ((reinterpret_cast<uintptr_t>(src) & 3) == 0);
-  int        hr[7][4];
-#pragma unroll
-  for (int r = 0; r < kBlurRows + 6; r++) {
-    const int sy = reflect101(min(y0 + r - 3, L.h + 2), L.h);
-    int       p[10];
-    blur_load10(src + (long long)sy * pitch, x0, L.w, fast, p);
-#pragma unroll
-    for (int k = 0; k < 6; k++)
-#pragma unroll
-      for (int i = 0; i < 4; i++) hr[k][i] = hr[k + 1][i];
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-      hr[6][i] = 18 * (p[i] + p[i + 6]) + 34 * (p[i + 1] + p[i + 5]) + 48 * (p[i + 2] + p[i + 4]) + 56 * p[i + 3];
-    if (r >= 6) {
-      const int oy = y0 + r - 6;
-      if (oy < L.h) {
-        uint32_t out = 0;
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-          const uint32_t sacc = 18u * (hr[0][i] + hr[6][i]) + 34u * (hr[1][i] + hr[5][i]) + 48u * (hr[2][i] + hr[4][i]) + 56u * hr[3][i];
-          out |= ((sacc + 32768u) >> 16) << (8 * i);
-        }
-        *reinterpret_cast<uint32_t*>(dst + (long long)oy * L.blurPitch + x0) = out;
-      }
-    }
+  const bool     al4 = ((pitch & 3) == 0) && ((reinterpret_cast<uintptr_t>(src) & 3) == 0);
+  const int      groups = (L.w + 3) >> 2, strips = L.blurTilesY;
+  // interior groups 1 .. gLast: x0 >= 4 and x0 + 8 <= w
+  const int gLast = (L.w - 8) >> 2, nInt = al4 ? max(gLast, 0) : 0, nEdge = groups - nInt;
+  const int intBlocks = (nInt * strips + 255) >> 8;
+  if (t < intBlocks) {
+    const int item = t * 256 + tid;
+    if (item >= nInt * strips) return;
+    const int strip = item / nInt, gi = 1 + item - strip * nInt;
+    blur_strip<true>(src, pitch, dst, L.blurPitch, L.w, L.h, gi * 4, strip * kBlurRows);
+  } else {
+    const int item = (t - intBlocks) * 256 + tid;
+    if (item >= nEdge * strips) return;
+    const int strip = item / nEdge, e = item - strip * nEdge;
+    const int gi = nInt == 0 ? e : (e == 0 ? 0 : gLast + e);  // group 0, then the trailing groups gLast+1 .. groups-1
+    blur_strip<false>(src, pitch, dst, L.blurPitch, L.w, L.h, gi * 4, strip * kBlurRows);
   }
 }
 
