@@ -324,9 +324,15 @@ int orbx_extractor::run(const uint8_t* d_imgs, int B, int rows, int cols, size_t
   }
   if (prof) HIP_TRY(hipEventRecord(ev[1], s));
   {
-    const int per = fastGrid / 8;  // order-table slots per XCD
-    hipLaunchKernelGGL(k_fast_cells, dim3(8 * ((per + kFastCellsPerBlock - 1) / kFastCellsPerBlock), B), dim3(256), 0, s, b, g,
-                       std::min(std::max(iniTh, 0), 255), std::min(std::max(minTh, 0), 255), fastGrid);
+    const int  per  = fastGrid / 8;  // order-table slots per XCD
+    const dim3 grid(8 * ((per + kFastCellsPerBlock - 1) / kFastCellsPerBlock), B);
+    const int  t1 = std::min(std::max(iniTh, 0), 255), t2 = std::min(std::max(minTh, 0), 255);
+    // pyramid levels are 64-byte pitched and 256-byte based; level 0 is the caller's buffer
+    const bool al4 = (step % 4 == 0) && (frameStride % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_imgs) & 3) == 0);
+    if (al4)
+      hipLaunchKernelGGL(k_fast_cells<true>, grid, dim3(256), 0, s, b, g, t1, t2, fastGrid);
+    else
+      hipLaunchKernelGGL(k_fast_cells<false>, grid, dim3(256), 0, s, b, g, t1, t2, fastGrid);
   }
   if (prof) HIP_TRY(hipEventRecord(ev[2], s));
   hipLaunchKernelGGL(k_octree, dim3(g.nlevels, B), dim3(kOctThreads), 0, s, b, g);

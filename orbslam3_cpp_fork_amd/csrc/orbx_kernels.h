@@ -196,6 +196,47 @@ __device__ __forceinline__ int fast_score(const uint8_t (*tile)[kFastTileMax], i
   return max(A, -Bm) - 1;
 }
 
+// ---- packed 16-bit lanes: two pixels per VGPR (v_pk_min_i16 / v_pk_max_i16 / v_pk_sub_i16) ----------------------
+typedef short pk16 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ pk16     pk_from(uint32_t u) { return __builtin_bit_cast(pk16, u); }
+__device__ __forceinline__ uint32_t pk_bits(pk16 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ pk16     pk_min(pk16 a, pk16 b) { return __builtin_elementwise_min(a, b); }
+__device__ __forceinline__ pk16     pk_max(pk16 a, pk16 b) { return __builtin_elementwise_max(a, b); }
+__device__ __forceinline__ pk16     pk_pair(int lo, int hi) { return pk_from((uint32_t)lo | ((uint32_t)hi << 16)); }  // 0 <= lo, hi < 65536
+
+// Corner scores of TWO pixels at once (low half: pixel A at cA, high half: pixel B at cB); same arithmetic as
+// fast_score, every min/max done on both 16-bit halves by one packed instruction.
+__device__ __forceinline__ void fast_score2(const uint8_t* __restrict__ cA, const uint8_t* __restrict__ cB, int ts, int* sA, int* sB) {
+  const int off[16] = {3 * ts,      3 * ts + 1,  2 * ts + 2,  ts + 3, 3, -ts + 3, -2 * ts + 2, -3 * ts + 1,
+                       -3 * ts,     -3 * ts - 1, -2 * ts - 2, -ts - 3, -3, ts - 3,  2 * ts - 2,  3 * ts - 1};
+  const pk16 v = pk_pair(cA[0], cB[0]);
+  pk16       d[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) d[k] = v - pk_pair(cA[off[k]], cB[off[k]]);
+  pk16 mn2[16], mx2[16], mn4[16], mx4[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    mn2[i] = pk_min(d[i], d[(i + 1) & 15]);
+    mx2[i] = pk_max(d[i], d[(i + 1) & 15]);
+  }
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    mn4[i] = pk_min(mn2[i], mn2[(i + 2) & 15]);
+    mx4[i] = pk_max(mx2[i], mx2[(i + 2) & 15]);
+  }
+  pk16 A = pk_pair(0xfc18, 0xfc18), Bm = pk_pair(1000, 1000);  // -1000 / +1000
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    const pk16 m9 = pk_min(pk_min(mn4[i], mn4[(i + 4) & 15]), d[(i + 8) & 15]);
+    const pk16 M9 = pk_max(pk_max(mx4[i], mx4[(i + 4) & 15]), d[(i + 8) & 15]);
+    A             = pk_max(A, m9);
+    Bm            = pk_min(Bm, M9);
+  }
+  const pk16 sc = pk_max(A, -Bm) - pk16{1, 1};
+  *sA           = sc.x;
+  *sB           = sc.y;
+}
+
 // Workgroup barrier that waits for this wave's LDS traffic only.  __syncthreads() also drains vmcnt, which would
 // stall every wave on the next cell's prefetch loads at the first barrier after they were issued.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -206,11 +247,12 @@ constexpr int kFastPrefetch      = 7;  // tile dwords a thread may hold in fligh
 struct FastCell {
   bool           valid;  // false: padding slot or a cell the reference skips (:782-793) / that has no interior
   int            cell, level, ci_i, ci_j, tw, th, iw, ih, pitch, n4, tw4;
+  int            ox;  // the tile is staged from the 4-byte aligned column below iniX: cell column x sits at LDS column x + ox
   unsigned       mT4;
-  bool           al4;
-  const uint8_t* img;
+  const uint8_t* img;  // row 0 of the tile at the ALIGNED column (AL4) / at iniX (byte path, ox = 0)
 };
 
+template <bool AL4>
 __device__ __forceinline__ FastCell fast_decode(const Bufs& b, const FrameGeom& g, int slot, int nslots, int f) {
   FastCell c;
   c.valid = false;
@@ -229,16 +271,20 @@ __device__ __forceinline__ FastCell fast_decode(const Bufs& b, const FrameGeom& 
   c.tw = maxX - iniX, c.th = maxY - iniY;
   c.iw = c.tw - 6, c.ih = c.th - 6;  // interior scored by cv::FAST
   if (c.iw <= 0 || c.ih <= 0) return c;
-  c.img = level_raw(b, g, level, f, &c.pitch) + (long long)iniY * c.pitch + iniX;
-  c.tw4 = (c.tw + 3) >> 2;
+  c.ox  = AL4 ? (iniX & 3) : 0;
+  c.img = level_raw(b, g, level, f, &c.pitch) + (long long)iniY * c.pitch + iniX - c.ox;
+  c.tw4 = (c.ox + c.tw + 3) >> 2;
   c.n4  = c.tw4 * c.th;
   c.mT4 = 0xffffffffu / (unsigned)c.tw4 + 1u;
-  c.al4 = ((c.pitch & 3) == 0) && ((reinterpret_cast<uintptr_t>(c.img) & 3) == 0);
   c.valid = true;
   return c;
 }
 
-// issue the global loads of a cell's tile: 4 pixels per thread-slot where rows are 4-byte aligned, bytes otherwise
+// Issue the global loads of a cell's tile.  AL4 (level base and pitch 4-byte aligned -- always true for pyramid
+// levels >= 1, and for level 0 when the caller's image is): one aligned 32-bit load per slot, starting at the aligned
+// column below iniX; the up-to-3 extra bytes on either side lie inside the image row (cells end >= 16 px before the
+// row end).  Otherwise byte loads.
+template <bool AL4>
 __device__ __forceinline__ void fast_prefetch(const FastCell& c, int tid, uint32_t (&r)[kFastPrefetch]) {
   if (!c.valid) return;
 #pragma unroll
@@ -247,20 +293,20 @@ __device__ __forceinline__ void fast_prefetch(const FastCell& c, int tid, uint32
     if (idx < c.n4) {
       const int      y = div_magic(idx, c.mT4), x = (idx - y * c.tw4) * 4;
       const uint8_t* src = c.img + (long long)y * c.pitch + x;
-      uint32_t       v;
-      if (c.al4 && x + 4 <= c.tw) {
-        v = *reinterpret_cast<const uint32_t*>(src);
+      if (AL4) {
+        r[k] = *reinterpret_cast<const uint32_t*>(src);
       } else {
-        v = src[0];
+        uint32_t v = src[0];
         if (x + 1 < c.tw) v |= (uint32_t)src[1] << 8;
         if (x + 2 < c.tw) v |= (uint32_t)src[2] << 16;
         if (x + 3 < c.tw) v |= (uint32_t)src[3] << 24;
+        r[k] = v;
       }
-      r[k] = v;
     }
   }
 }
 
+template <bool AL4>
 __global__ __launch_bounds__(256) void k_fast_cells(Bufs b, FrameGeom g, int iniTh, int minTh, int nslots) {
   constexpr int                     kMaxInt = (kFastTileMax - 6) * (kFastTileMax - 6);  // interior pixels of the largest tile
   __shared__ __align__(16) uint8_t  tile[kFastTileMax][kFastTileMax];   // pixels
@@ -268,6 +314,8 @@ __global__ __launch_bounds__(256) void k_fast_cells(Bufs b, FrameGeom g, int ini
   __shared__ unsigned short         candList[kMaxInt];                  // pass-1 survivors (pixel index in the interior)
   __shared__ unsigned short         kpList[kMaxInt / 2 + 64];           // NMS survivors under either threshold
   __shared__ int                    candCount, kpCount, cnt1, cnt2;
+  constexpr int                     ts = kFastTileMax;  // row stride of the tile
+  const uint8_t*                    tl = &tile[0][0];
   // Workgroup b walks kFastCellsPerBlock consecutive slots of XCD (b % 8)'s list in the host-built order table
   // (whole cell ROWS dealt to the 8 XCDs, balanced by cell count: horizontally adjacent cells share 128-B lines and
   // the 6-px overlap, so they sit behind one L2).  While a cell is processed the NEXT cell's tile is already in
@@ -276,21 +324,22 @@ __global__ __launch_bounds__(256) void k_fast_cells(Bufs b, FrameGeom g, int ini
   const int xcd = blockIdx.x & 7, k0 = (blockIdx.x >> 3) * kFastCellsPerBlock;
   const int lowTh = max(min(iniTh, minTh), 1);
   uint32_t  pre[kFastPrefetch];
-  FastCell  cur = fast_decode(b, g, k0 * 8 + xcd, nslots, f);
-  fast_prefetch(cur, tid, pre);
+  FastCell  cur = fast_decode<AL4>(b, g, k0 * 8 + xcd, nslots, f);
+  fast_prefetch<AL4>(cur, tid, pre);
   for (int cc = 0; cc < kFastCellsPerBlock; cc++) {
     FastCell nxt;
     nxt.valid = false, nxt.cell = -1;
-    if (cc + 1 < kFastCellsPerBlock) nxt = fast_decode(b, g, (k0 + cc + 1) * 8 + xcd, nslots, f);
+    if (cc + 1 < kFastCellsPerBlock) nxt = fast_decode<AL4>(b, g, (k0 + cc + 1) * 8 + xcd, nslots, f);
     if (!cur.valid) {
       if (cur.cell >= 0 && tid == 0) b.cellCount[(long long)f * g.totalCells + cur.cell] = 0;
       cur = nxt;
-      fast_prefetch(cur, tid, pre);
+      fast_prefetch<AL4>(cur, tid, pre);
       continue;
     }
     const LevelGeom& L  = g.lv[cur.level];
     const int        iw = cur.iw, ih = cur.ih;
     const unsigned   mIw = iw == 1 ? 0u : 0xffffffffu / (unsigned)iw + 1u;  // interior-width divider for idx -> (row, col)
+    const int        ox3 = 3 + cur.ox;  // LDS column of interior column 0
     // registers -> LDS (kFastTileMax is a multiple of 4: aligned; spill past tw stays inside the row)
 #pragma unroll
     for (int k = 0; k < kFastPrefetch; k++) {
@@ -303,43 +352,72 @@ __global__ __launch_bounds__(256) void k_fast_cells(Bufs b, FrameGeom g, int ini
     }
     if (tid == 0) candCount = 0, kpCount = 0, cnt1 = 0, cnt2 = 0;
     __syncthreads();
-    fast_prefetch(nxt, tid, pre);  // in flight during the four passes below
+    fast_prefetch<AL4>(nxt, tid, pre);  // in flight during the four passes below
     const int npix = iw * ih;
     // Pass 1 -- necessary condition + compaction.  A 9-arc of the 16-pixel circle always contains 4 CONSECUTIVE even
     // circle positions (0, 2, .., 14), so a pixel can only score >= lowTh if four consecutive even positions are all
     // darker than v - lowTh or all brighter than v + lowTh.  Survivors go (any order) to an LDS list so that the
     // full score below runs with all lanes busy.
-    for (int idx = tid; idx < ((npix + 63) & ~63); idx += 256) {
-      bool keep = false;
-      if (idx < npix) {
-        const int q = div_magic(idx, mIw), y = 3 + q, x = 3 + idx - q * iw;
-        const int v = tile[y][x];
-        const int lo = v - lowTh, hi = v + lowTh;
-        const int p0 = tile[y + 3][x], p2 = tile[y + 2][x + 2], p4 = tile[y][x + 3], p6 = tile[y - 2][x + 2];
-        const int p8 = tile[y - 3][x], p10 = tile[y - 2][x - 2], p12 = tile[y][x - 3], p14 = tile[y + 2][x - 2];
-        unsigned dk = (p0 < lo) | ((p2 < lo) << 1) | ((p4 < lo) << 2) | ((p6 < lo) << 3) | ((p8 < lo) << 4) | ((p10 < lo) << 5) |
-                      ((p12 < lo) << 6) | ((p14 < lo) << 7);
-        unsigned br = (p0 > hi) | ((p2 > hi) << 1) | ((p4 > hi) << 2) | ((p6 > hi) << 3) | ((p8 > hi) << 4) | ((p10 > hi) << 5) |
-                      ((p12 > hi) << 6) | ((p14 > hi) << 7);
-        dk |= dk << 8, br |= br << 8;  // cyclic
-        dk &= dk >> 1, dk &= dk >> 2;  // bit i = positions i..i+3 all set
-        br &= br >> 1, br &= br >> 2;
-        keep = ((dk | br) & 0xffu) != 0;
+    // Two pixels per lane (A = pair index j, B = j + npairs) with packed 16-bit min/max: "four consecutive even
+    // positions all below lo" <=> min over the 8 windows of (max of the window) < lo, and symmetrically for hi.
+    const int  npairs = (npix + 1) >> 1;
+    const pk16 tpk    = pk_pair(lowTh, lowTh);
+    for (int j = tid; j < ((npairs + 63) & ~63); j += 256) {
+      bool keepA = false, keepB = false;
+      int  idxA = 0, idxB = 0;
+      if (j < npairs) {
+        idxA = j;
+        idxB = min(j + npairs, npix - 1);
+        const int      qa = div_magic(idxA, mIw), qb = div_magic(idxB, mIw);
+        const uint8_t* cA = tl + (3 + qa) * ts + ox3 + idxA - qa * iw;
+        const uint8_t* cB = tl + (3 + qb) * ts + ox3 + idxB - qb * iw;
+        const pk16     v  = pk_pair(cA[0], cB[0]);
+        const pk16     lo = v - tpk, hi = v + tpk;
+        pk16           p[8];
+        p[0] = pk_pair(cA[3 * ts], cB[3 * ts]);
+        p[1] = pk_pair(cA[2 * ts + 2], cB[2 * ts + 2]);
+        p[2] = pk_pair(cA[3], cB[3]);
+        p[3] = pk_pair(cA[-2 * ts + 2], cB[-2 * ts + 2]);
+        p[4] = pk_pair(cA[-3 * ts], cB[-3 * ts]);
+        p[5] = pk_pair(cA[-2 * ts - 2], cB[-2 * ts - 2]);
+        p[6] = pk_pair(cA[-3], cB[-3]);
+        p[7] = pk_pair(cA[2 * ts - 2], cB[2 * ts - 2]);
+        pk16 mx2[8], mn2[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          mx2[i] = pk_max(p[i], p[(i + 1) & 7]);
+          mn2[i] = pk_min(p[i], p[(i + 1) & 7]);
+        }
+        pk16 dmin = pk_max(mx2[0], mx2[2]), bmax = pk_min(mn2[0], mn2[2]);
+#pragma unroll
+        for (int i = 1; i < 8; i++) {
+          dmin = pk_min(dmin, pk_max(mx2[i], mx2[(i + 2) & 7]));  // smallest "max of 4 consecutive"
+          bmax = pk_max(bmax, pk_min(mn2[i], mn2[(i + 2) & 7]));  // largest  "min of 4 consecutive"
+        }
+        const uint32_t neg = pk_bits(dmin - lo) | pk_bits(hi - bmax);  // a negative half = that pixel passes
+        keepA              = (neg & 0x8000u) != 0;
+        keepB              = (neg & 0x80000000u) != 0 && (j + npairs < npix);
       }
-      const unsigned long long bal = __ballot(keep);
+      const unsigned long long balA = __ballot(keepA), balB = __ballot(keepB);
       int                      base = 0;
-      if (lane == 0 && bal) base = atomicAdd(&candCount, __popcll(bal));
+      if (lane == 0 && (balA | balB)) base = atomicAdd(&candCount, __popcll(balA) + __popcll(balB));
       base = __shfl(base, 0, 64);
-      if (keep) candList[base + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)idx;
+      const unsigned long long below = (1ull << lane) - 1ull;
+      if (keepA) candList[base + __popcll(balA & below)] = (unsigned short)idxA;
+      if (keepB) candList[base + __popcll(balA) + __popcll(balB & below)] = (unsigned short)idxB;
     }
     lds_barrier();
     // Pass 2 -- full corner score of the survivors
     const int ncand = candCount;
-    for (int k = tid; k < ncand; k += 256) {
-      const int idx = candList[k];
-      const int q = div_magic(idx, mIw), y = 3 + q, x = 3 + idx - q * iw;
-      const int s = fast_score(tile, x, y);
-      score[y][x] = (uint8_t)(s >= lowTh ? s : 0);  // scores below both thresholds are never corners
+    const int nhalf = (ncand + 1) >> 1;  // two candidates per lane: k and k + nhalf
+    for (int k = tid; k < nhalf; k += 256) {
+      const int idxA = candList[k], idxB = candList[min(k + nhalf, ncand - 1)];
+      const int qa = div_magic(idxA, mIw), ya = 3 + qa, xa = ox3 + idxA - qa * iw;
+      const int qb = div_magic(idxB, mIw), yb = 3 + qb, xb = ox3 + idxB - qb * iw;
+      int       sA, sB;
+      fast_score2(tl + ya * ts + xa, tl + yb * ts + xb, ts, &sA, &sB);
+      score[ya][xa] = (uint8_t)(sA >= lowTh ? sA : 0);  // scores below both thresholds are never corners
+      score[yb][xb] = (uint8_t)(sB >= lowTh ? sB : 0);  // (B duplicates A's last element when ncand is odd: same value)
     }
     lds_barrier();
     // Pass 3 -- strict 3x3 NMS under both thresholds, over the survivors only.  Flags go to a sparse list.
@@ -348,7 +426,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(Bufs b, FrameGeom g, int ini
       int  idx = 0;
       if (k < ncand) {
         idx = candList[k];
-        const int q = div_magic(idx, mIw), y = 3 + q, x = 3 + idx - q * iw;
+        const int q = div_magic(idx, mIw), y = 3 + q, x = ox3 + idx - q * iw;
         const int s = score[y][x];
         if (s > 0) {
           int m1 = 0, m2 = 0;  // max neighbour score under each threshold
@@ -392,8 +470,8 @@ __global__ __launch_bounds__(256) void k_fast_cells(Bufs b, FrameGeom g, int ini
           const unsigned ot = kpList[o];
           rank += ((ot & selB) && (int)(ot & 0x3fff) < idx) ? 1 : 0;
         }
-        const int q = div_magic(idx, mIw), y = 3 + q, x = 3 + idx - q * iw;
-        out[rank]   = (uint32_t)(x + cur.ci_j * L.wCell) | ((uint32_t)(y + cur.ci_i * L.hCell) << 12) | ((uint32_t)score[y][x] << 24);
+        const int q = div_magic(idx, mIw), y = 3 + q, x = ox3 + idx - q * iw;
+        out[rank]   = (uint32_t)(x - cur.ox + cur.ci_j * L.wCell) | ((uint32_t)(y + cur.ci_i * L.hCell) << 12) | ((uint32_t)score[y][x] << 24);
       }
     }
     lds_barrier();  // tile / score / lists are rewritten by the next cell
