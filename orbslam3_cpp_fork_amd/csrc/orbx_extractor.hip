@@ -275,7 +275,7 @@ int orbx_extractor::ensureWorkspace(int rows, int cols, int B) {
   const orbx::FrameGeom& g  = geom;
   const size_t           nb = (size_t)B;
   const size_t           np = nb * g.totalSlots, nn = nb * g.totalNodes;
-  if (dPyr.ensure(nb * g.pyrBytes) || dBlur.ensure(nb * g.blurBytes) || dSlots.ensure(np) || dCellCount.ensure(nb * g.totalCells) ||
+  if (dPyr.ensure(nb * g.pyrBytes + 256) || dBlur.ensure(nb * g.blurBytes + 256) || dSlots.ensure(np) || dCellCount.ensure(nb * g.totalCells) ||
       dCand.ensure(np) || dOrdA.ensure(np) || dOrdB.ensure(np) || dNodeOfA.ensure(np) || dNodeOfB.ensure(np) || dP.ensure(np) ||
       dQv.ensure(np) || dNodesA.ensure(nn) || dNodesB.ensure(nn) || dStartCnt.ensure(nn) || dEndCnt.ensure(nn) || dD.ensure(nn) ||
       dDIndex.ensure(nn) || dNCh.ensure(nn) || dPushOff.ensure(nn) || dMultiOff.ensure(nn) || dKeptRank.ensure(nn) || dVA.ensure(nn) ||
@@ -347,7 +347,7 @@ int orbx_extractor::run(const uint8_t* d_imgs, int B, int rows, int cols, size_t
   {
     const int nbPerFrame = (g.totalKp + 3) / 4;
     hipLaunchKernelGGL(k_orient_describe, dim3(8 * ((B + 7) / 8) * nbPerFrame), dim3(256), 0, s, b, g, dPattern.p, d_counts, d_kps, d_desc, cap, B,
-                       nbPerFrame);
+                       nbPerFrame, getenv("ORBX_DBG_SKIP") ? atoi(getenv("ORBX_DBG_SKIP")) : 0);
   }
   if (prof) {
     HIP_TRY(hipEventRecord(ev[6], s));

@@ -744,7 +744,7 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {  // cv::fast
 __constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};  // src/ORBextractor.cc:448-464
 
 __global__ __launch_bounds__(256) void k_orient_describe(Bufs b, FrameGeom g, const PatternTab* __restrict__ pat, const int* counts,
-                                                          KpRec* kps, uint8_t* desc, int cap, int nframes, int nbPerFrame) {
+                                                          KpRec* kps, uint8_t* desc, int cap, int nframes, int nbPerFrame, int dbgSkip) {
   // 1-D grid with frame -> XCD affinity: all workgroups of frame f run on XCD f % 8 (blocks b, b + 8, ... share an
   // L2), so the raw + blurred levels of a frame (1.9 MB at VGA) are pulled into ONE 4-MiB L2 instead of all eight.
   const int lane = threadIdx.x & 63;
@@ -753,11 +753,20 @@ __global__ __launch_bounds__(256) void k_orient_describe(Bufs b, FrameGeom g, co
   const int i = (q % nbPerFrame) * 4 + (threadIdx.x >> 6);
   const int n = counts[2 * f];
   if (i >= n) return;
+  // level of keypoint i: all level counts are fetched at once (independent loads), then a register-only search --
+  // a `while (i >= base + lc[level])` walk would be a chain of up to 8 dependent global loads per wave
   const int* lc = b.lvlCount + (long long)f * g.nlevels;
-  int        level = 0, base = 0;
-  while (level + 1 < g.nlevels && i >= base + lc[level]) {
-    base += lc[level];
-    level++;
+  int        cnts[kMaxLevels];
+#pragma unroll
+  for (int l = 0; l < kMaxLevels; l++) cnts[l] = l < g.nlevels ? lc[l] : 0;
+  const int row = b.outIdx[(long long)f * g.totalKp + i];  // output row: needed last, requested first
+  int       level = 0, base = 0;
+#pragma unroll
+  for (int l = 0; l < kMaxLevels - 1; l++) {
+    if (l + 1 < g.nlevels && i >= base + cnts[l] && level == l) {
+      base += cnts[l];
+      level = l + 1;
+    }
   }
   const LevelGeom& L  = g.lv[level];
   const uint32_t   r  = b.lvlKp[(long long)f * g.totalKp + L.kpBase + (i - base)];
@@ -765,19 +774,35 @@ __global__ __launch_bounds__(256) void k_orient_describe(Bufs b, FrameGeom g, co
   // ---- orientation on the raw level
   int            pitch;
   const uint8_t* img    = level_raw(b, g, level, f, &pitch);
-  const uint8_t* center = img + (long long)py * pitch + px;
-  int            m10 = 0, m01 = 0;
-  {
-    const int half = lane >> 5, u = (lane & 31) - 15;  // lanes 0..30 -> +v rows, 32..62 -> -v rows
-    if ((lane & 31) < 31) {
-      if (half == 0) m10 += u * center[u];  // v = 0 row once
+  int m10 = 0, m01 = 0;
+  if (!(dbgSkip & 1)) {
+    // The 31-row disc is read as 31 x 9 aligned dwords (columns ax .. ax+35 cover px-15 .. px+15): 5 independent
+    // 32-bit loads per lane instead of 16 byte loads.  umax[|v|] (src/ORBextractor.cc:448-464) is nibble-packed.
+    const unsigned long long kUmax = 0x3689ABCDDEEEFFFFull;  // nibble v = umax[v]: 15,15,15,15,14,14,14,13,13,12,11,10,9,8,6,3
+    const int                ax    = (px - kHalfPatch) & ~3;
+    const uint8_t*           rp    = img + (long long)(py - kHalfPatch) * pitch + ax;
+    const bool               al4   = ((pitch & 3) == 0) && ((reinterpret_cast<uintptr_t>(img) & 3) == 0);
 #pragma unroll
-      for (int v = 1; v <= kHalfPatch; v++) {
-        const int d = c_umax[v];
-        if (u >= -d && u <= d) {
-          const int val = half == 0 ? center[u + v * pitch] : center[u - v * pitch];
+    for (int k = 0; k < 5; k++) {
+      const int idx = lane + 64 * k;
+      if (idx < 31 * 9) {
+        const int      rr = idx / 9, cc = idx - rr * 9;
+        const uint8_t* p  = rp + (long long)rr * pitch + cc * 4;
+        uint32_t       dw;
+        if (al4) {
+          dw = *reinterpret_cast<const uint32_t*>(p);
+        } else {
+          dw = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+        }
+        const int v  = rr - kHalfPatch;
+        const int d  = (int)((kUmax >> (4 * (v < 0 ? -v : v))) & 15ull);
+        const int u0 = ax + cc * 4 - px;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const int u   = u0 + j;
+          const int val = (u >= -d && u <= d) ? (int)((dw >> (8 * j)) & 0xffu) : 0;
           m10 += u * val;
-          m01 += half == 0 ? v * val : -v * val;
+          m01 += v * val;
         }
       }
     }
@@ -793,8 +818,25 @@ __global__ __launch_bounds__(256) void k_orient_describe(Bufs b, FrameGeom g, co
   float       sn, cs;
   orbport::sincosf_port<false>(angle * factorPI, &sn, &cs);
   const float    a = cs, bb = sn;
-  const uint8_t* bl = b.blur + (long long)f * g.blurBytes + L.blurOff + (long long)py * L.blurPitch + px;
-  const int      bp = L.blurPitch;
+  // The 512 taps land anywhere in a 37 x 37 window; gathering them straight from global memory costs one cache-line
+  // lookup per lane per tap (the kernel was bound by the texture addresser, not by VALU or HBM).  The window is first
+  // staged into this wave's LDS slice with coalesced aligned 32-bit loads (11 dwords x 37 rows), then the taps are
+  // LDS byte reads.
+  __shared__ __align__(16) uint8_t patch[4][37 * 44];
+  uint8_t*       pw  = patch[threadIdx.x >> 6];
+  const int      ax  = (px - 18) & ~3;  // aligned first column; the blurred level base and pitch are 64-byte aligned
+  const uint8_t* blr = b.blur + (long long)f * g.blurBytes + L.blurOff + (long long)(py - 18) * L.blurPitch + ax;
+#pragma unroll
+  for (int k = 0; k < 7; k++) {
+    const int idx = lane + 64 * k;
+    if (idx < 37 * 11 && !(dbgSkip & 2)) {
+      const int rr = idx / 11, cc = idx - rr * 11;
+      *reinterpret_cast<uint32_t*>(pw + rr * 44 + cc * 4) = *reinterpret_cast<const uint32_t*>(blr + (long long)rr * L.blurPitch + cc * 4);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // single wave: its own LDS writes are complete
+  const uint8_t* bl = pw + 18 * 44 + (px - ax);  // window centre
+  const int      bp = 44;
   unsigned long long words[4];
 #pragma unroll
   for (int w = 0; w < 4; w++) {
@@ -803,11 +845,10 @@ __global__ __launch_bounds__(256) void k_orient_describe(Bufs b, FrameGeom g, co
     const float x0 = (float)p4.x, y0 = (float)p4.y, x1 = (float)p4.z, y1 = (float)p4.w;
     const int   r0 = __float2int_rn(x0 * bb + y0 * a), c0 = __float2int_rn(x0 * a - y0 * bb);
     const int   r1 = __float2int_rn(x1 * bb + y1 * a), c1 = __float2int_rn(x1 * a - y1 * bb);
-    const int   t0 = bl[r0 * bp + c0], t1 = bl[r1 * bp + c1];
+    const int   t0 = (dbgSkip & 4) ? r0 : bl[r0 * bp + c0], t1 = (dbgSkip & 4) ? c1 : bl[r1 * bp + c1];
     words[w]       = __ballot(t0 < t1);
   }
   // ---- output row
-  const int row = b.outIdx[(long long)f * g.totalKp + i];
   if (row < cap) {
     if (lane < 4) {
       unsigned long long wv = lane == 0 ? words[0] : lane == 1 ? words[1] : lane == 2 ? words[2] : words[3];

@@ -161,6 +161,7 @@ struct GroupArgs {
   int            q_astride, t_astride;  // in floats
   int            th, strict_lt, check_ori;
   float          ratio;
+  int            dstar;      // pruning bound: candidates at distance >= dstar cannot change any decision (see prune_bound)
   uint32_t*      topk;       // [nqe][kTopK]
   int*           nvalid;     // [nqe] candidates seen by the top-k pass
   int*           binOf;      // [nq]
@@ -232,12 +233,83 @@ __global__ __launch_bounds__(256) void k_group_topk(GroupArgs a0) {
           const int row = t_idx ? t_idx[pos] : pos;
           return (t_valid && !t_valid[row]) ? -1 : row;
         },
-        [](int, int) { return true; }, out, &nv);
+        [dstar = a.dstar](int, int d) { return d < dstar; }, out, &nv);
   }
   if ((threadIdx.x & 63) == 0) {
 #pragma unroll
     for (int j = 0; j < kTopK; j++) a.topk[(size_t)e * kTopK + j] = out[j];
-    a.nvalid[e] = nv;
+    a.nvalid[e] = nv;  // candidates below the pruning bound
+  }
+}
+
+// Brute-force form of the top-K pass (one group, identity index lists -- the per-frame stream case): one QUERY per
+// lane, the train descriptors walk by as wave-uniform operands (scalar loads), so a candidate costs 8 xor + 8
+// popcount-accumulate per lane and nothing else; the sorted per-lane K-list is only touched for the rare candidate
+// below the pruning bound.  k_group_topk (one wave per query, lanes stride the candidates) stays for the grouped
+// DBoW2 form, whose candidate lists are short and differ per query.
+constexpr int kBfTile = 256;  // train rows staged in LDS per step (8 KB)
+
+__global__ __launch_bounds__(256) void k_bf_topk(GroupArgs a0) {
+  __shared__ __align__(16) uint4 tile[2][kBfTile][2];  // double-buffered train descriptors
+  __shared__ uint8_t             tval[2][kBfTile];
+  const GroupArgs a   = pair_view(a0, blockIdx.y);
+  const int       tid = threadIdx.x;
+  const int       nq  = a.d_nq ? *a.d_nq : a.nq;
+  const int       nt  = a.d_nt ? *a.d_nt : a.nt;
+  if ((int)blockIdx.x * 256 >= nq) return;  // whole workgroup
+  const int  e      = blockIdx.x * 256 + tid;
+  const bool active = e < nq && !(a.q_valid && !a.q_valid[e]);
+  uint4      a0v = make_uint4(0, 0, 0, 0), a1v = a0v;
+  if (e < nq) {
+    a0v = *reinterpret_cast<const uint4*>(a.q + (size_t)e * 32);
+    a1v = *reinterpret_cast<const uint4*>(a.q + (size_t)e * 32 + 16);
+  }
+  uint32_t k[kTopK];
+#pragma unroll
+  for (int j = 0; j < kTopK; j++) k[j] = kEmpty;
+  int       cnt   = 0;
+  const int dstar = a.dstar;
+  // stage tile 0
+  auto stage = [&](int buf, int base) {
+    const int row = base + tid;
+    if (row < nt) {
+      tile[buf][tid][0] = *reinterpret_cast<const uint4*>(a.t + (size_t)row * 32);
+      tile[buf][tid][1] = *reinterpret_cast<const uint4*>(a.t + (size_t)row * 32 + 16);
+      tval[buf][tid]    = a.t_valid ? a.t_valid[row] : 1;
+    }
+  };
+  stage(0, 0);
+  __syncthreads();
+  int buf = 0;
+  for (int base = 0; base < nt; base += kBfTile) {
+    if (base + kBfTile < nt) stage(buf ^ 1, base + kBfTile);  // next tile in flight while this one is consumed
+    const int n = min(kBfTile, nt - base);
+#pragma unroll 4
+    for (int r = 0; r < n; r++) {
+      const uint4 b0 = tile[buf][r][0], b1 = tile[buf][r][1];  // same LDS address in every lane: broadcast
+      const int   d  = __popc(a0v.x ^ b0.x) + __popc(a0v.y ^ b0.y) + __popc(a0v.z ^ b0.z) + __popc(a0v.w ^ b0.w) + __popc(a1v.x ^ b1.x) +
+                    __popc(a1v.y ^ b1.y) + __popc(a1v.z ^ b1.z) + __popc(a1v.w ^ b1.w);
+      if (d < dstar && active && tval[buf][r]) {
+        cnt++;
+        uint32_t key = ((uint32_t)d << kPosBits) | (uint32_t)(base + r);
+#pragma unroll
+        for (int j = 0; j < kTopK; j++) {
+          if (key < k[j]) {
+            const uint32_t t = k[j];
+            k[j]             = key;
+            key              = t;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    buf ^= 1;
+  }
+  if (e < nq) {
+    uint4* o = reinterpret_cast<uint4*>(a.topk + (size_t)e * kTopK);
+    o[0]     = make_uint4(k[0], k[1], k[2], k[3]);
+    o[1]     = make_uint4(k[4], k[5], k[6], k[7]);
+    a.nvalid[e] = cnt;
   }
 }
 
@@ -490,6 +562,7 @@ struct WindowArgs {
   float                  minX, minY, gwInv, ghInv, r;
   int                    th, check_ori;
   float                  ratio;
+  int                    dstar;
   uint32_t*              topk;
   int*                   nvalid;
   int *                  m12, *m21, *binOf, *nmatches;
@@ -532,7 +605,7 @@ __global__ __launch_bounds__(256) void k_window_topk(WindowArgs a) {
             const float dx = ar.kp2[i2].x - x, dy = ar.kp2[i2].y - y;
             return (fabsf(dx) < ar.r && fabsf(dy) < ar.r) ? i2 : -1;
           },
-          [](int, int) { return true; }, out, &nv);
+          [dstar = ar.dstar](int, int d) { return d < dstar; }, out, &nv);
     }
   }
   if ((threadIdx.x & 63) == 0) {
@@ -664,6 +737,17 @@ __global__ __launch_bounds__(64) void k_window_resolve(WindowArgs a) {
   if (lane == 0) *a.nmatches = nmatches;
 }
 
+// Exact pruning bound of the top-K pass.  A match needs best <= th (or < th) and best < ratio * second.  Let D* be the
+// smallest integer with (float)th < ratio * (float)D*.  A candidate at distance >= D* can never be the best of an
+// accepted match (D* > th), and as a runner-up it passes the ratio test for EVERY admissible best -- exactly as a
+// missing runner-up (256 / INT_MAX) does.  So the K-lists only need the candidates below D*; the rest are dropped
+// after one compare, before any sorting work.  (Random 256-bit descriptors sit around 128 +- 8: almost all pruned.)
+int prune_bound(int th, float ratio) {
+  int d = th + 1;
+  while (d < 257 && !((float)th < ratio * (float)d)) d++;
+  return d;
+}
+
 template <class T>
 struct DBuf {
   T*     p = nullptr;
@@ -783,7 +867,12 @@ void orbm_three_maxima(const int* counts, int len, int* ind1, int* ind2, int* in
 
 static int launch_groups(orbm_matcher* h, GroupArgs& a, int nq_cap, hipStream_t s, int npairs = 1) {
   const int nqe = a.q_idx ? a.nqe : nq_cap;
-  if (nqe > 0) hipLaunchKernelGGL(k_group_topk, dim3((nqe + 3) / 4, npairs), dim3(256), 0, s, a);
+  if (nqe > 0) {
+    if (a.q_idx)
+      hipLaunchKernelGGL(k_group_topk, dim3((nqe + 3) / 4, npairs), dim3(256), 0, s, a);
+    else
+      hipLaunchKernelGGL(k_bf_topk, dim3((nqe + 255) / 256, npairs), dim3(256), 0, s, a);
+  }
   hipLaunchKernelGGL(k_group_resolve, dim3(npairs), dim3(kResolveThreads), 0, s, a);
   HIP_TRYM(hipGetLastError());
   return 0;
@@ -861,7 +950,7 @@ int orbm_match_groups(orbm_t* h, const uint8_t* q, int nq, const uint8_t* t, int
   a.t_off = grouped ? h->toff.p : nullptr, a.t_idx = grouped ? h->tidx.p : nullptr;
   a.q_valid = q_valid ? h->dqv.p : nullptr, a.t_valid = t_valid ? h->dtv.p : nullptr;
   a.q_angle = h->qa.p, a.t_angle = h->ta.p, a.q_astride = 1, a.t_astride = 1;
-  a.th = th, a.strict_lt = strict_lt, a.check_ori = check_ori, a.ratio = ratio;
+  a.th = th, a.strict_lt = strict_lt, a.check_ori = check_ori, a.ratio = ratio, a.dstar = prune_bound(th, ratio);
   a.topk = h->topk.p, a.nvalid = h->nvalid.p, a.binOf = h->binOf.p;
   a.match_t_of_q = h->mq.p, a.match_q_of_t = h->mt.p, a.nmatches = h->nm.p;
   int rc = launch_groups(h, a, nq, s);
@@ -893,7 +982,7 @@ int orbm_match_bruteforce_device(orbm_t* h, const uint8_t* d_q, const orbx_keypo
   a.q = d_q, a.t = d_t, a.d_nq = d_nq, a.d_nt = d_nt, a.nq = cap_q, a.nt = cap_t, a.ngroups = 1, a.nqe = cap_q;
   a.q_angle = d_q_kp ? &d_q_kp->angle : nullptr, a.t_angle = d_t_kp ? &d_t_kp->angle : nullptr;
   a.q_astride = a.t_astride = sizeof(orbx_keypoint_t) / 4;
-  a.th = th, a.strict_lt = strict_lt, a.check_ori = check_ori, a.ratio = ratio;
+  a.th = th, a.strict_lt = strict_lt, a.check_ori = check_ori, a.ratio = ratio, a.dstar = prune_bound(th, ratio);
   a.topk = h->topk.p, a.nvalid = h->nvalid.p, a.binOf = h->binOf.p;
   a.match_t_of_q = d_match_t_of_q, a.match_q_of_t = h->mt.p, a.nmatches = d_nmatches;
   return launch_groups(h, a, cap_q, stream ? (hipStream_t)stream : h->stream);
@@ -919,7 +1008,7 @@ int orbm_match_pairs_device(orbm_t* h, const uint8_t* d_desc, const orbx_keypoin
   a.q = d_desc, a.t = d_desc, a.nq = cap, a.nt = cap, a.ngroups = 1, a.nqe = cap;
   a.q_angle = d_kps ? &d_kps->angle : nullptr, a.t_angle = a.q_angle;
   a.q_astride = a.t_astride = sizeof(orbx_keypoint_t) / 4;
-  a.th = th, a.strict_lt = strict_lt, a.check_ori = check_ori, a.ratio = ratio;
+  a.th = th, a.strict_lt = strict_lt, a.check_ori = check_ori, a.ratio = ratio, a.dstar = prune_bound(th, ratio);
   a.topk = h->topk.p, a.nvalid = h->nvalid.p, a.binOf = h->binOf.p;
   a.match_t_of_q = d_match_t_of_q, a.match_q_of_t = h->mt.p, a.nmatches = d_nmatches;
   a.pairs = d_pairs, a.counts = d_counts, a.cap = cap;
@@ -989,7 +1078,7 @@ int orbm_match_window(orbm_t* h, const uint8_t* d1, const orbx_keypoint_t* kp1, 
   a.d1 = h->dq.p, a.d2 = h->dt.p, a.kp1 = h->kp1.p, a.kp2 = h->kp2.p, a.n1 = n1, a.n2 = n2, a.ng = ng;
   a.g_idx = h->gidx.p, a.g_cx = h->gcx.p, a.g_cy = h->gcy.p, a.prev = h->prev.p;
   a.minX = min_x, a.minY = min_y, a.gwInv = gwInv, a.ghInv = ghInv, a.r = (float)window;
-  a.th = th, a.check_ori = check_ori, a.ratio = ratio;
+  a.th = th, a.check_ori = check_ori, a.ratio = ratio, a.dstar = prune_bound(th, ratio);
   a.topk = h->topk.p, a.nvalid = h->nvalid.p, a.m12 = h->mq.p, a.m21 = h->mt.p, a.binOf = h->binOf.p, a.nmatches = h->nm.p;
   if (n1 > 0) hipLaunchKernelGGL(k_window_topk, dim3((n1 + 3) / 4), dim3(256), 0, s, a);
   hipLaunchKernelGGL(k_window_resolve, dim3(1), dim3(64), 0, s, a);
