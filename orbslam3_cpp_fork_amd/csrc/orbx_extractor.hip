@@ -95,6 +95,7 @@ struct orbx_extractor {
   orbx::Bufs      bufs{};
   DevBuf<uint8_t> dPyr, dBlur, dQv, dStage, dDescOut;
   DevBuf<int2>    dXtab, dYtab;
+  DevBuf<int4>    dCellDesc;
   DevBuf<int>     dCellOrder, dCellSlot, dCellCount, dOrdA, dOrdB, dNodeOfA, dNodeOfB, dP, dD, dDIndex, dNCh, dPushOff, dMultiOff, dKeptRank, dVA,
       dVB, dCandCount, dLvlCount, dOutIdx, dCounts;
   DevBuf<uint32_t>           dSlots, dCand, dLvlKp;
@@ -257,6 +258,32 @@ int orbx_extractor::makeGeometry(int rows, int cols) {
   }
   if (dCellOrder.ensure(cellOrder.size() + 1)) return -3;
   HIP_TRY(hipMemcpy(dCellOrder.p, cellOrder.data(), cellOrder.size() * sizeof(int), hipMemcpyHostToDevice));
+  // pre-decoded geometry per order slot (FastCellDesc in orbx_kernels.h)
+  {
+    std::vector<int4> desc(2 * cellOrder.size());
+    for (size_t sidx = 0; sidx < cellOrder.size(); sidx++) {
+      int4 d0 = make_int4(-1, 0, 0, 0), d1 = make_int4(0, 0, 0, 0);
+      const int cell = cellOrder[sidx];
+      if (cell >= 0) {
+        int l = 0;
+        while (l + 1 < nlevels && cell >= g.lv[l + 1].cellBase) l++;
+        const LevelGeom& L = g.lv[l];
+        const int ci = cell - L.cellBase, ci_i = ci / L.nCols, ci_j = ci - ci_i * L.nCols;
+        const int iniY = kMinBorder + ci_i * L.hCell, iniX = kMinBorder + ci_j * L.wCell;
+        int       tw = 0, th = 0, valid = 0;
+        if (!(iniY >= L.maxBY - 3 || iniX >= L.maxBX - 6)) {
+          tw = std::min(iniX + L.wCell + 6, L.maxBX) - iniX;
+          th = std::min(iniY + L.hCell + 6, L.maxBY) - iniY;
+          valid = (tw - 6 > 0 && th - 6 > 0) ? 1 : 0;
+        }
+        d0 = make_int4(cell, l, iniX | (iniY << 16), tw | (th << 8) | (valid << 16));
+        d1 = make_int4((ci_j * L.wCell) | ((ci_i * L.hCell) << 16), L.slotBase + cellSlot[cell], L.pyrOff + iniY * L.pitch + iniX, L.pitch);
+      }
+      desc[2 * sidx] = d0, desc[2 * sidx + 1] = d1;
+    }
+    if (dCellDesc.ensure(desc.size() + 2)) return -3;
+    HIP_TRY(hipMemcpy(dCellDesc.p, desc.data(), desc.size() * sizeof(int4), hipMemcpyHostToDevice));
+  }
   // upload tables
   if (dXtab.ensure(xt.size() + 1) || dYtab.ensure(yt.size() + 1) || dCellSlot.ensure(cellSlot.size() + 1)) return -3;
   HIP_TRY(hipMemcpy(dXtab.p, xt.data(), xt.size() * sizeof(int2), hipMemcpyHostToDevice));
@@ -283,7 +310,7 @@ int orbx_extractor::ensureWorkspace(int rows, int cols, int B) {
       dLvlCount.ensure(nb * g.nlevels) || dOutIdx.ensure(nb * g.totalKp))
     return -3;
   orbx::Bufs& b = bufs;
-  b.pyr = dPyr.p, b.blur = dBlur.p, b.xtab = dXtab.p, b.ytab = dYtab.p, b.cellSlot = dCellSlot.p, b.cellOrder = dCellOrder.p, b.slots = dSlots.p;
+  b.pyr = dPyr.p, b.blur = dBlur.p, b.xtab = dXtab.p, b.ytab = dYtab.p, b.cellSlot = dCellSlot.p, b.cellOrder = dCellOrder.p, b.cellDesc = dCellDesc.p, b.slots = dSlots.p;
   b.cellCount = dCellCount.p, b.cand = dCand.p, b.ordA = dOrdA.p, b.ordB = dOrdB.p, b.nodeOfA = dNodeOfA.p, b.nodeOfB = dNodeOfB.p;
   b.P = dP.p, b.qv = dQv.p, b.nodesA = dNodesA.p, b.nodesB = dNodesB.p, b.startCnt = dStartCnt.p, b.endCnt = dEndCnt.p, b.D = dD.p;
   b.dIndex = dDIndex.p, b.nCh = dNCh.p, b.pushOff = dPushOff.p, b.multiOff = dMultiOff.p, b.keptRank = dKeptRank.p, b.vA = dVA.p;
@@ -329,10 +356,11 @@ int orbx_extractor::run(const uint8_t* d_imgs, int B, int rows, int cols, size_t
     const int  t1 = std::min(std::max(iniTh, 0), 255), t2 = std::min(std::max(minTh, 0), 255);
     // pyramid levels are 64-byte pitched and 256-byte based; level 0 is the caller's buffer
     const bool al4 = (step % 4 == 0) && (frameStride % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_imgs) & 3) == 0);
+    const int dbg = getenv("ORBX_DBG_SKIP_FAST") ? atoi(getenv("ORBX_DBG_SKIP_FAST")) : 0;  // ablation switch (tuning)
     if (al4)
-      hipLaunchKernelGGL(k_fast_cells<true>, grid, dim3(256), 0, s, b, g, t1, t2, fastGrid);
+      hipLaunchKernelGGL(k_fast_cells<true>, grid, dim3(256), 0, s, b, g, t1, t2, fastGrid, dbg);
     else
-      hipLaunchKernelGGL(k_fast_cells<false>, grid, dim3(256), 0, s, b, g, t1, t2, fastGrid);
+      hipLaunchKernelGGL(k_fast_cells<false>, grid, dim3(256), 0, s, b, g, t1, t2, fastGrid, dbg);
   }
   if (prof) HIP_TRY(hipEventRecord(ev[2], s));
   hipLaunchKernelGGL(k_octree, dim3(g.nlevels, B), dim3(kOctThreads), 0, s, b, g);
@@ -438,7 +466,7 @@ void orbx_destroy(orbx_t* h) {
     for (auto& slot : h->ev)
       for (auto& e : slot) hipEventDestroy(e);
   h->dPyr.release(), h->dBlur.release(), h->dQv.release(), h->dStage.release(), h->dDescOut.release(), h->dXtab.release(), h->dYtab.release();
-  h->dCellOrder.release(), h->dCellSlot.release(), h->dCellCount.release(), h->dOrdA.release(), h->dOrdB.release(), h->dNodeOfA.release(), h->dNodeOfB.release();
+  h->dCellDesc.release(), h->dCellOrder.release(), h->dCellSlot.release(), h->dCellCount.release(), h->dOrdA.release(), h->dOrdB.release(), h->dNodeOfA.release(), h->dNodeOfB.release();
   h->dP.release(), h->dD.release(), h->dDIndex.release(), h->dNCh.release(), h->dPushOff.release(), h->dMultiOff.release();
   h->dKeptRank.release(), h->dVA.release(), h->dVB.release(), h->dCandCount.release(), h->dLvlCount.release(), h->dOutIdx.release();
   h->dCounts.release(), h->dSlots.release(), h->dCand.release(), h->dLvlKp.release(), h->dNodesA.release(), h->dNodesB.release();

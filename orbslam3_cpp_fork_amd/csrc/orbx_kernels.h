@@ -36,6 +36,7 @@ struct Bufs {
   const int2*    ytab;
   const int*     cellSlot;   // [totalCells] slot base of each cell inside the frame's slot array
   const int*     cellOrder;  // [fastGrid] XCD-aware launch order of the FAST cells (-1 = padding)
+  const int4*    cellDesc;   // [fastGrid][2] pre-decoded cell geometry for that order (see FastCellDesc)
   uint32_t*      slots;      // [B][totalSlots] per-cell candidate slots written by FAST
   int*           cellCount;  // [B][totalCells]
   // quadtree workspace, per frame: point arrays [totalSlots], node arrays [totalNodes]
@@ -252,27 +253,37 @@ struct FastCell {
   const uint8_t* img;  // row 0 of the tile at the ALIGNED column (AL4) / at iniX (byte path, ox = 0)
 };
 
+// Host-built descriptor of one order slot (two int4 = 32 bytes, fetched with one scalar load):
+//   d0 = {cell (-1 = padding), level, iniX | iniY << 16, tw | th << 8 | valid << 16}
+//   d1 = {x offset | y offset << 16 of the cell inside the level (ci_j * wCell, ci_i * hCell),
+//         first candidate slot of the cell inside the frame's slot array, byte offset of (iniX, iniY) inside the
+//         frame's pyramid block (levels >= 1), row pitch (levels >= 1)}
+// It replaces a per-cell walk over FrameGeom::lv[] (a chain of dependent scalar loads) done twice per cell.
 template <bool AL4>
-__device__ __forceinline__ FastCell fast_decode(const Bufs& b, const FrameGeom& g, int slot, int nslots, int f) {
+__device__ __forceinline__ FastCell fast_decode(const Bufs& b, const FrameGeom& g, int slot, int nslots, int f, int* xoff, int* yoff,
+                                                int* slotOff) {
   FastCell c;
   c.valid = false;
-  c.cell  = slot < nslots ? b.cellOrder[slot] : -1;
+  c.cell  = -1;
+  if (slot >= nslots) return c;
+  const int4 d0 = b.cellDesc[2 * slot], d1 = b.cellDesc[2 * slot + 1];
+  c.cell = d0.x;
   if (c.cell < 0) return c;
-  int level = 0;
-  while (level + 1 < g.nlevels && c.cell >= g.lv[level + 1].cellBase) level++;
-  const LevelGeom& L  = g.lv[level];
-  const int        ci = c.cell - L.cellBase;
-  c.level = level;
-  c.ci_i = ci / L.nCols, c.ci_j = ci - c.ci_i * L.nCols;
-  const int iniY = kMinBorder + c.ci_i * L.hCell, iniX = kMinBorder + c.ci_j * L.wCell;
-  c.tw = c.th = c.iw = c.ih = 0;
-  if (iniY >= L.maxBY - 3 || iniX >= L.maxBX - 6) return c;  // skip rules (:782-793); count stays 0
-  const int maxY = min(iniY + L.hCell + 6, L.maxBY), maxX = min(iniX + L.wCell + 6, L.maxBX);
-  c.tw = maxX - iniX, c.th = maxY - iniY;
-  c.iw = c.tw - 6, c.ih = c.th - 6;  // interior scored by cv::FAST
-  if (c.iw <= 0 || c.ih <= 0) return c;
-  c.ox  = AL4 ? (iniX & 3) : 0;
-  c.img = level_raw(b, g, level, f, &c.pitch) + (long long)iniY * c.pitch + iniX - c.ox;
+  c.level = d0.y;
+  c.tw = d0.w & 0xff, c.th = (d0.w >> 8) & 0xff;
+  c.iw = c.tw - 6, c.ih = c.th - 6;
+  c.ci_i = c.ci_j = 0;
+  *xoff = d1.x & 0xffff, *yoff = (d1.x >> 16) & 0xffff, *slotOff = d1.y;
+  if (!((d0.w >> 16) & 1)) return c;  // cell skipped by the reference (:782-793) or without interior: count stays 0
+  const int iniX = d0.z & 0xffff, iniY = (d0.z >> 16) & 0xffff;
+  c.ox = AL4 ? (iniX & 3) : 0;
+  if (c.level == 0) {
+    c.pitch = b.img0Pitch;
+    c.img   = b.img0 + (long long)f * b.img0FrameStride + (long long)iniY * c.pitch + iniX - c.ox;
+  } else {
+    c.pitch = d1.w;
+    c.img   = b.pyr + (long long)f * g.pyrBytes + d1.z - c.ox;
+  }
   c.tw4 = (c.ox + c.tw + 3) >> 2;
   c.n4  = c.tw4 * c.th;
   c.mT4 = 0xffffffffu / (unsigned)c.tw4 + 1u;
@@ -307,7 +318,7 @@ __device__ __forceinline__ void fast_prefetch(const FastCell& c, int tid, uint32
 }
 
 template <bool AL4>
-__global__ __launch_bounds__(256) void k_fast_cells(Bufs b, FrameGeom g, int iniTh, int minTh, int nslots) {
+__global__ __launch_bounds__(256) void k_fast_cells(Bufs b, FrameGeom g, int iniTh, int minTh, int nslots, int dbgSkip) {
   constexpr int                     kMaxInt = (kFastTileMax - 6) * (kFastTileMax - 6);  // interior pixels of the largest tile
   __shared__ __align__(16) uint8_t  tile[kFastTileMax][kFastTileMax];   // pixels
   __shared__ __align__(16) uint8_t  score[kFastTileMax][kFastTileMax];  // corner score (0 = not a corner at lowTh)
@@ -324,20 +335,20 @@ __global__ __launch_bounds__(256) void k_fast_cells(Bufs b, FrameGeom g, int ini
   const int xcd = blockIdx.x & 7, k0 = (blockIdx.x >> 3) * kFastCellsPerBlock;
   const int lowTh = max(min(iniTh, minTh), 1);
   uint32_t  pre[kFastPrefetch];
-  FastCell  cur = fast_decode<AL4>(b, g, k0 * 8 + xcd, nslots, f);
+  int       xoff = 0, yoff = 0, slotOff = 0, nxoff = 0, nyoff = 0, nslotOff = 0;
+  FastCell  cur = fast_decode<AL4>(b, g, k0 * 8 + xcd, nslots, f, &xoff, &yoff, &slotOff);
   fast_prefetch<AL4>(cur, tid, pre);
   for (int cc = 0; cc < kFastCellsPerBlock; cc++) {
     FastCell nxt;
     nxt.valid = false, nxt.cell = -1;
-    if (cc + 1 < kFastCellsPerBlock) nxt = fast_decode<AL4>(b, g, (k0 + cc + 1) * 8 + xcd, nslots, f);
+    if (cc + 1 < kFastCellsPerBlock) nxt = fast_decode<AL4>(b, g, (k0 + cc + 1) * 8 + xcd, nslots, f, &nxoff, &nyoff, &nslotOff);
     if (!cur.valid) {
       if (cur.cell >= 0 && tid == 0) b.cellCount[(long long)f * g.totalCells + cur.cell] = 0;
-      cur = nxt;
+      cur = nxt, xoff = nxoff, yoff = nyoff, slotOff = nslotOff;
       fast_prefetch<AL4>(cur, tid, pre);
       continue;
     }
-    const LevelGeom& L  = g.lv[cur.level];
-    const int        iw = cur.iw, ih = cur.ih;
+    const int iw = cur.iw, ih = cur.ih;
     const unsigned   mIw = iw == 1 ? 0u : 0xffffffffu / (unsigned)iw + 1u;  // interior-width divider for idx -> (row, col)
     const int        ox3 = 3 + cur.ox;  // LDS column of interior column 0
     // registers -> LDS (kFastTileMax is a multiple of 4: aligned; spill past tw stays inside the row)
@@ -365,7 +376,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(Bufs b, FrameGeom g, int ini
     for (int j = tid; j < ((npairs + 63) & ~63); j += 256) {
       bool keepA = false, keepB = false;
       int  idxA = 0, idxB = 0;
-      if (j < npairs) {
+      if (j < npairs && !(dbgSkip & 1)) {
         idxA = j;
         idxB = min(j + npairs, npix - 1);
         const int      qa = div_magic(idxA, mIw), qb = div_magic(idxB, mIw);
@@ -410,7 +421,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(Bufs b, FrameGeom g, int ini
     // Pass 2 -- full corner score of the survivors
     const int ncand = candCount;
     const int nhalf = (ncand + 1) >> 1;  // two candidates per lane: k and k + nhalf
-    for (int k = tid; k < nhalf; k += 256) {
+    for (int k = tid; k < ((dbgSkip & 2) ? 0 : nhalf); k += 256) {
       const int idxA = candList[k], idxB = candList[min(k + nhalf, ncand - 1)];
       const int qa = div_magic(idxA, mIw), ya = 3 + qa, xa = ox3 + idxA - qa * iw;
       const int qb = div_magic(idxB, mIw), yb = 3 + qb, xb = ox3 + idxB - qb * iw;
@@ -459,7 +470,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(Bufs b, FrameGeom g, int ini
     const unsigned selB = cnt1 > 0 ? 0x8000u : 0x4000u;
     // Pass 4 -- row-major emission order (cv::FAST's): rank of every selected keypoint = number of selected keypoints
     // with a smaller pixel index.  The list is short (a few to a few dozen entries per cell).
-    uint32_t* out = b.slots + (long long)f * g.totalSlots + L.slotBase + b.cellSlot[cur.cell];
+    uint32_t* out = b.slots + (long long)f * g.totalSlots + slotOff;
     if (tid == 0) b.cellCount[(long long)f * g.totalCells + cur.cell] = cnt1 > 0 ? cnt1 : cnt2;
     for (int e = tid; e < nk; e += 256) {
       const unsigned me = kpList[e];
@@ -471,11 +482,11 @@ __global__ __launch_bounds__(256) void k_fast_cells(Bufs b, FrameGeom g, int ini
           rank += ((ot & selB) && (int)(ot & 0x3fff) < idx) ? 1 : 0;
         }
         const int q = div_magic(idx, mIw), y = 3 + q, x = ox3 + idx - q * iw;
-        out[rank]   = (uint32_t)(x - cur.ox + cur.ci_j * L.wCell) | ((uint32_t)(y + cur.ci_i * L.hCell) << 12) | ((uint32_t)score[y][x] << 24);
+        out[rank]   = (uint32_t)(x - cur.ox + xoff) | ((uint32_t)(y + yoff) << 12) | ((uint32_t)score[y][x] << 24);
       }
     }
     lds_barrier();  // tile / score / lists are rewritten by the next cell
-    cur = nxt;
+    cur = nxt, xoff = nxoff, yoff = nyoff, slotOff = nslotOff;
   }
 }
 
