@@ -357,10 +357,27 @@ int orbx_extractor::run(const uint8_t* d_imgs, int B, int rows, int cols, size_t
     // pyramid levels are 64-byte pitched and 256-byte based; level 0 is the caller's buffer
     const bool al4 = (step % 4 == 0) && (frameStride % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_imgs) & 3) == 0);
     const int dbg = getenv("ORBX_DBG_SKIP_FAST") ? atoi(getenv("ORBX_DBG_SKIP_FAST")) : 0;  // ablation switch (tuning)
-    if (al4)
-      hipLaunchKernelGGL(k_fast_cells<true>, grid, dim3(256), 0, s, b, g, t1, t2, fastGrid, dbg);
-    else
-      hipLaunchKernelGGL(k_fast_cells<false>, grid, dim3(256), 0, s, b, g, t1, t2, fastGrid, dbg);
+    // tile dwords per thread for this geometry: tiles are staged from the aligned column below iniX (up to +3)
+    int maxN4 = 0;
+    for (int l = 0; l < g.nlevels; l++) maxN4 = std::max(maxN4, ((3 + g.lv[l].wCell + 6 + 3) / 4) * (g.lv[l].hCell + 6));
+    const int npre = (maxN4 + 255) / 256;
+#define ORBX_LAUNCH_FAST(AL, NP) hipLaunchKernelGGL((k_fast_cells<AL, NP>), grid, dim3(256), 0, s, b, g, t1, t2, fastGrid, dbg)
+    if (al4) {
+      if (npre <= 2)
+        ORBX_LAUNCH_FAST(true, 2);
+      else if (npre <= 3)
+        ORBX_LAUNCH_FAST(true, 3);
+      else if (npre <= 4)
+        ORBX_LAUNCH_FAST(true, 4);
+      else
+        ORBX_LAUNCH_FAST(true, kFastPrefetchMax);
+    } else {
+      if (npre <= 3)
+        ORBX_LAUNCH_FAST(false, 3);
+      else
+        ORBX_LAUNCH_FAST(false, kFastPrefetchMax);
+    }
+#undef ORBX_LAUNCH_FAST
   }
   if (prof) HIP_TRY(hipEventRecord(ev[2], s));
   hipLaunchKernelGGL(k_octree, dim3(g.nlevels, B), dim3(kOctThreads), 0, s, b, g);

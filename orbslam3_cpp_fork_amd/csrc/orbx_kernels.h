@@ -243,7 +243,7 @@ __device__ __forceinline__ void fast_score2(const uint8_t* __restrict__ cA, cons
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 constexpr int kFastCellsPerBlock = 4;  // cells walked by one (persistent) workgroup
-constexpr int kFastPrefetch      = 7;  // tile dwords a thread may hold in flight: ceil(20 * 77 / 256)
+constexpr int kFastPrefetchMax   = 7;  // tile dwords a thread may hold in flight: ceil(20 * 77 / 256) for the largest tile
 
 struct FastCell {
   bool           valid;  // false: padding slot or a cell the reference skips (:782-793) / that has no interior
@@ -295,11 +295,11 @@ __device__ __forceinline__ FastCell fast_decode(const Bufs& b, const FrameGeom& 
 // levels >= 1, and for level 0 when the caller's image is): one aligned 32-bit load per slot, starting at the aligned
 // column below iniX; the up-to-3 extra bytes on either side lie inside the image row (cells end >= 16 px before the
 // row end).  Otherwise byte loads.
-template <bool AL4>
-__device__ __forceinline__ void fast_prefetch(const FastCell& c, int tid, uint32_t (&r)[kFastPrefetch]) {
+template <bool AL4, int NPRE>
+__device__ __forceinline__ void fast_prefetch(const FastCell& c, int tid, uint32_t (&r)[NPRE]) {
   if (!c.valid) return;
 #pragma unroll
-  for (int k = 0; k < kFastPrefetch; k++) {
+  for (int k = 0; k < NPRE; k++) {
     const int idx = tid + k * 256;
     if (idx < c.n4) {
       const int      y = div_magic(idx, c.mT4), x = (idx - y * c.tw4) * 4;
@@ -317,7 +317,8 @@ __device__ __forceinline__ void fast_prefetch(const FastCell& c, int tid, uint32
   }
 }
 
-template <bool AL4>
+// NPRE = tile dwords per thread for THIS image geometry (ceil(max tile dwords / 256); 3 at VGA, 7 worst case).
+template <bool AL4, int NPRE>
 __global__ __launch_bounds__(256) void k_fast_cells(Bufs b, FrameGeom g, int iniTh, int minTh, int nslots, int dbgSkip) {
   constexpr int                     kMaxInt = (kFastTileMax - 6) * (kFastTileMax - 6);  // interior pixels of the largest tile
   __shared__ __align__(16) uint8_t  tile[kFastTileMax][kFastTileMax];   // pixels
@@ -334,10 +335,10 @@ __global__ __launch_bounds__(256) void k_fast_cells(Bufs b, FrameGeom g, int ini
   const int f = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
   const int xcd = blockIdx.x & 7, k0 = (blockIdx.x >> 3) * kFastCellsPerBlock;
   const int lowTh = max(min(iniTh, minTh), 1);
-  uint32_t  pre[kFastPrefetch];
+  uint32_t  pre[NPRE];
   int       xoff = 0, yoff = 0, slotOff = 0, nxoff = 0, nyoff = 0, nslotOff = 0;
   FastCell  cur = fast_decode<AL4>(b, g, k0 * 8 + xcd, nslots, f, &xoff, &yoff, &slotOff);
-  fast_prefetch<AL4>(cur, tid, pre);
+  fast_prefetch<AL4, NPRE>(cur, tid, pre);
   for (int cc = 0; cc < kFastCellsPerBlock; cc++) {
     FastCell nxt;
     nxt.valid = false, nxt.cell = -1;
@@ -345,7 +346,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(Bufs b, FrameGeom g, int ini
     if (!cur.valid) {
       if (cur.cell >= 0 && tid == 0) b.cellCount[(long long)f * g.totalCells + cur.cell] = 0;
       cur = nxt, xoff = nxoff, yoff = nyoff, slotOff = nslotOff;
-      fast_prefetch<AL4>(cur, tid, pre);
+      fast_prefetch<AL4, NPRE>(cur, tid, pre);
       continue;
     }
     const int iw = cur.iw, ih = cur.ih;
@@ -353,7 +354,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(Bufs b, FrameGeom g, int ini
     const int        ox3 = 3 + cur.ox;  // LDS column of interior column 0
     // registers -> LDS (kFastTileMax is a multiple of 4: aligned; spill past tw stays inside the row)
 #pragma unroll
-    for (int k = 0; k < kFastPrefetch; k++) {
+    for (int k = 0; k < NPRE; k++) {
       const int idx = tid + k * 256;
       if (idx < cur.n4) {
         const int y = div_magic(idx, cur.mT4), x = (idx - y * cur.tw4) * 4;
@@ -363,7 +364,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(Bufs b, FrameGeom g, int ini
     }
     if (tid == 0) candCount = 0, kpCount = 0, cnt1 = 0, cnt2 = 0;
     __syncthreads();
-    fast_prefetch<AL4>(nxt, tid, pre);  // in flight during the four passes below
+    fast_prefetch<AL4, NPRE>(nxt, tid, pre);  // in flight during the four passes below
     const int npix = iw * ih;
     // Pass 1 -- necessary condition + compaction.  A 9-arc of the 16-pixel circle always contains 4 CONSECUTIVE even
     // circle positions (0, 2, .., 14), so a pixel can only score >= lowTh if four consecutive even positions are all
