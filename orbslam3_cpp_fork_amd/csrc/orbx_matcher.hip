@@ -284,11 +284,12 @@ __global__ __launch_bounds__(256) void k_bf_topk(GroupArgs a0) {
   for (int base = 0; base < nt; base += kBfTile) {
     if (base + kBfTile < nt) stage(buf ^ 1, base + kBfTile);  // next tile in flight while this one is consumed
     const int n = min(kBfTile, nt - base);
-#pragma unroll 4
-    for (int r = 0; r < n; r++) {
+    auto dist = [&](int r) {
       const uint4 b0 = tile[buf][r][0], b1 = tile[buf][r][1];  // same LDS address in every lane: broadcast
-      const int   d  = __popc(a0v.x ^ b0.x) + __popc(a0v.y ^ b0.y) + __popc(a0v.z ^ b0.z) + __popc(a0v.w ^ b0.w) + __popc(a1v.x ^ b1.x) +
-                    __popc(a1v.y ^ b1.y) + __popc(a1v.z ^ b1.z) + __popc(a1v.w ^ b1.w);
+      return __popc(a0v.x ^ b0.x) + __popc(a0v.y ^ b0.y) + __popc(a0v.z ^ b0.z) + __popc(a0v.w ^ b0.w) + __popc(a1v.x ^ b1.x) +
+             __popc(a1v.y ^ b1.y) + __popc(a1v.z ^ b1.z) + __popc(a1v.w ^ b1.w);
+    };
+    auto consider = [&](int r, int d) {
       if (d < dstar && active && tval[buf][r]) {
         cnt++;
         uint32_t key = ((uint32_t)d << kPosBits) | (uint32_t)(base + r);
@@ -301,7 +302,19 @@ __global__ __launch_bounds__(256) void k_bf_topk(GroupArgs a0) {
           }
         }
       }
+    };
+    // four rows per step: eight LDS reads and 64 xor/popcount in one straight block, one pruning test for all four
+    int r = 0;
+    for (; r + 4 <= n; r += 4) {
+      const int d0 = dist(r), d1 = dist(r + 1), d2 = dist(r + 2), d3 = dist(r + 3);
+      if (min(min(d0, d1), min(d2, d3)) < dstar) {
+        consider(r, d0);
+        consider(r + 1, d1);
+        consider(r + 2, d2);
+        consider(r + 3, d3);
+      }
     }
+    for (; r < n; r++) consider(r, dist(r));
     __syncthreads();
     buf ^= 1;
   }
