@@ -1,0 +1,110 @@
+"""BASELINE.json configs 3-5 on the GPU: stream extract + match, stereo pair on two concurrent handles, 8-camera rig."""
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _same(ref, got):
+    rc0, k0, d0 = ref
+    rc1, k1, d1 = got
+    return rc0 == rc1 and len(k0) == len(k1) and (k0.view(np.uint32) == k1.view(np.uint32)).all() and (d0 == d1).all()
+
+
+def test_config3_stream_extract_and_match(oracle):
+    """EuRoC-sized mono stream (752x480): every frame extracted, then matched against its predecessor on the device;
+    per-frame matches equal the oracle's SearchByBoW loop."""
+    import torch
+
+    from orbslam3_cpp_fork_amd import synth
+    from orbslam3_cpp_fork_amd._lib import KP_DTYPE
+    from orbslam3_cpp_fork_amd.extractor import ORBextractor
+    from orbslam3_cpp_fork_amd.matcher import ORBmatcher
+
+    B, h, w = 6, 480, 752
+    frames = synth.make_stream(h, w, B, camera_idx=11)
+    ex, mt = ORBextractor(1000), ORBmatcher(0.7, True)
+    cap = ex.max_keypoints(h, w)
+    ts = torch.cuda.Stream()
+    with torch.cuda.stream(ts):
+        d_imgs = torch.from_numpy(frames).cuda()
+        d_kps = torch.zeros((B, cap, 7), dtype=torch.float32, device="cuda")
+        d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
+        d_cnt = torch.zeros((B, 2), dtype=torch.int32, device="cuda")
+        pairs = torch.from_numpy(np.stack([np.arange(B - 1), np.arange(1, B)], 1).astype(np.int32)).cuda()
+        d_match = torch.zeros((B - 1, cap), dtype=torch.int32, device="cuda")
+        d_nm = torch.zeros(B - 1, dtype=torch.int32, device="cuda")
+        ex.extract_batch_device(d_imgs, B, h, w, w, h * w, d_kps, d_desc, d_cnt, cap, (0, 1000), stream=ts.cuda_stream)
+        mt.match_pairs_device(d_desc, d_kps, d_cnt, cap, pairs, B - 1, d_match, d_nm, stream=ts.cuda_stream)
+    torch.cuda.synchronize()
+    cnt, nm, match = d_cnt.cpu().numpy(), d_nm.cpu().numpy(), d_match.cpu().numpy()
+    oex = oracle.OracleExtractor(1000)
+    res = [oex(f, (0, 1000)) for f in frames]
+    for f in range(B):
+        n = int(cnt[f, 0])
+        k = d_kps[f, :n].cpu().numpy().view(KP_DTYPE).reshape(-1)
+        assert _same(res[f], (int(cnt[f, 1]), k, d_desc[f, :n].cpu().numpy()))
+    for p in range(B - 1):
+        (_, k0, d0), (_, k1, d1) = res[p], res[p + 1]
+        n0, mq, _ = oracle.match_groups(d0, d1, k0["angle"], k1["angle"], th=50, ratio=0.7, check_ori=True)
+        assert n0 == int(nm[p]) and (match[p, : len(k0)] == mq).all()
+        assert n0 > 200
+
+
+def test_config4_stereo_two_handles_two_threads(oracle):
+    """KITTI-sized stereo pair (1241x376, 2000 features/image, lapping {0,0}): the reference runs the left and right
+    extractor objects on two std::threads (src/Frame.cc:202-205); two handles must work concurrently."""
+    from orbslam3_cpp_fork_amd import synth
+    from orbslam3_cpp_fork_amd.extractor import ORBextractor
+
+    left, right = synth.make_stereo_pair(376, 1241, camera_idx=5)
+    exs = [ORBextractor(2000), ORBextractor(2000)]
+    out = [None, None]
+
+    def work(i, img):
+        for _ in range(3):  # repeated calls on the same handle
+            out[i] = exs[i](img, None, (0, 0))
+
+    th = [threading.Thread(target=work, args=(i, im)) for i, im in enumerate((left, right))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    oex = oracle.OracleExtractor(2000)
+    assert _same(oex(left, (0, 0)), out[0]) and _same(oex(right, (0, 0)), out[1])
+    assert len(out[0][1]) > 1800
+    # mvImagePyramid of both eyes stays retrievable (ComputeStereoMatches reads it, src/Frame.cc:950)
+    assert (exs[1].pyramid_level(3) == oex.pyramid_level(3)).all()
+
+
+def test_config5_rig_of_8_cameras(oracle):
+    """8 synthetic 1920x1080 cameras in one device batch (what one GPU processes when the rig is not sharded)."""
+    import torch
+
+    from orbslam3_cpp_fork_amd import synth
+    from orbslam3_cpp_fork_amd._lib import KP_DTYPE
+    from orbslam3_cpp_fork_amd.extractor import ORBextractor
+
+    B, h, w = 8, 1080, 1920
+    frames = np.stack([synth.make_frame(h, w, camera_idx=c) for c in range(B)])
+    ex = ORBextractor(1000)
+    cap = ex.max_keypoints(h, w)
+    ts = torch.cuda.Stream()
+    with torch.cuda.stream(ts):
+        d_imgs = torch.from_numpy(frames).cuda()
+        d_kps = torch.zeros((B, cap, 7), dtype=torch.float32, device="cuda")
+        d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
+        d_cnt = torch.zeros((B, 2), dtype=torch.int32, device="cuda")
+        ex.extract_batch_device(d_imgs, B, h, w, w, h * w, d_kps, d_desc, d_cnt, cap, (0, 1000), stream=ts.cuda_stream)
+    torch.cuda.synchronize()
+    cnt = d_cnt.cpu().numpy()
+    oex = oracle.OracleExtractor(1000)
+    for f in (0, 3, 7):
+        n = int(cnt[f, 0])
+        k = d_kps[f, :n].cpu().numpy().view(KP_DTYPE).reshape(-1)
+        ref = oex(frames[f], (0, 1000))
+        assert _same(ref, (int(cnt[f, 1]), k, d_desc[f, :n].cpu().numpy()))
+        # W = 1920 > 1000: keypoints right of x = 1000 fill the front in natural order
+        assert ref[0] > 0 and (k["x"][: ref[0]] > 1000).all() and (k["x"][ref[0]:] <= 1000).all()
