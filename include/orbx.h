@@ -87,6 +87,9 @@ int  orbx_get_stage_ms(orbx_t* h, float* ms /* ORBX_NUM_STAGES */);
 int orbx_debug_blurred_level(orbx_t* h, int frame, int level, uint8_t* dst, size_t dst_step, int* rows, int* cols);
 int orbx_debug_level_candidates(orbx_t* h, int frame, int level, uint32_t* out, int cap);
 int orbx_debug_level_keypoints(orbx_t* h, int frame, int level, uint32_t* out, int cap);
+/* Tuning hook (set ORBX_DBG_OCT=1 before orbx_create): per (frame, level) of the last batch
+ * {sort cycles, total cycles, division steps, sorts} of the quadtree kernel. Returns the number of values. */
+int orbx_debug_octree_times(orbx_t* h, long long* out, int cap);
 /* PMC calibration: stream nbytes of scratch memory with `width` (1, 4 or 16) bytes per lane per load. */
 int orbx_debug_calib_read(orbx_t* h, long long nbytes, int width);
 /* Device run of DistributeOctTree alone on caller-supplied candidates (host arrays). */

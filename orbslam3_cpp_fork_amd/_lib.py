@@ -38,6 +38,7 @@ SIGNATURES = {
     "orbx_debug_blurred_level": (_i, [_vp, _i, _i, _vp, _sz, _ip, _ip]),
     "orbx_debug_level_candidates": (_i, [_vp, _i, _i, _vp, _i]),
     "orbx_debug_level_keypoints": (_i, [_vp, _i, _i, _vp, _i]),
+    "orbx_debug_octree_times": (_i, [_vp, _vp, _i]),
     "orbx_debug_calib_read": (_i, [_vp, C.c_longlong, _i]),
     "orbx_debug_octree_device": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _ip]),
     "orbm_create": (_i, [C.POINTER(_vp), _i]),

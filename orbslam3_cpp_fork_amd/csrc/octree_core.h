@@ -28,6 +28,11 @@
 #else
 #define OT_HD
 #endif
+#if defined(__HIP_DEVICE_COMPILE__)
+#define OT_CLOCK() ((long long)__builtin_readcyclecounter())
+#else
+#define OT_CLOCK() 0LL
+#endif
 
 namespace orbx {
 
@@ -65,6 +70,7 @@ struct OtArgs {
   // outputs
   uint32_t* outKp;  // kept candidates (same packing), list order
   int*      outCount;
+  long long* dbgT;  // optional diagnostic stamps (device tuning builds): [0] sort cycles, [1] total cycles, [2] division steps, [3] sorts
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -179,13 +185,14 @@ OT_HD inline int ot_partition_pivot(unsigned long long* b, int first, int last) 
 }
 
 // depth_limit < 0 -> the library's own 2*floor(log2(n)); tests pass small values to reach the heap path.
-OT_HD inline void ot_std_sort(unsigned long long* b, int n, int depth_limit = -1) {
+// `stk` = 3 x 64 ints of work-list storage (the device passes LDS: private arrays would live in scratch memory).
+OT_HD inline void ot_std_sort(unsigned long long* b, int n, int depth_limit, int* stk) {
   if (n <= 0) return;
   int lg = 0;
   while ((1 << (lg + 1)) <= n) lg++;
   int depth0 = depth_limit < 0 ? 2 * lg : depth_limit;
   // __introsort_loop with an explicit stack (the two sub-ranges are disjoint, order of visiting is free)
-  int sf[64], sl[64], sd[64], sp = 0;
+  int *sf = stk, *sl = stk + 64, *sd = stk + 128, sp = 0;
   sf[0] = 0, sl[0] = n, sd[0] = depth0, sp = 1;
   while (sp > 0) {
     --sp;
@@ -213,6 +220,11 @@ OT_HD inline void ot_std_sort(unsigned long long* b, int n, int depth_limit = -1
   }
 }
 
+OT_HD inline void ot_std_sort(unsigned long long* b, int n, int depth_limit = -1) {
+  int stk[192];
+  ot_std_sort(b, n, depth_limit, stk);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Execution contexts.  A context offers: tid, nt, sync(), scan4() (exclusive scan of one Int4 per
 // thread across the workgroup, returning the grand total too), bcast() and min_reduce().
@@ -225,13 +237,179 @@ struct HostCtx {
     Int4 z = {{0, 0, 0, 0}};
     return z;
   }
-  int min_reduce(int v) { return v; }
+  int  min_reduce(int v) { return v; }
+  void sort(unsigned long long* buf, int n) { ot_std_sort(buf, n); }
 };
 
 #if defined(__HIPCC__)
+// ------------------------------------------------------------------------------------------------
+// Wave-parallel re-enactment of libstdc++ std::sort for n <= 256 records (one wave, record j lives in lane j % 64,
+// register slot j / 64).  It performs exactly the swaps / moves of ot_std_sort -- the element order after every
+// partition and every insertion is identical -- but the sequential scans of the library algorithm
+//   while (comp(*lo, pivot)) ++lo;      while (comp(pivot, *hi)) --hi;      while (comp(val, *next)) shift
+// are answered with one ballot + find-first/last-bit, and a run of shifts is one cross-lane move.  A single lane
+// walking the same algorithm through LDS needs ~2000 dependent LDS round trips (~100 us) for the ~100 nodes of a level;
+// this needs a few hundred wave instructions.  Falls back to the serial code if the heap-sort path would be taken.
+// ------------------------------------------------------------------------------------------------
+template <int R>
+struct WaveSort {
+  unsigned long long   v[R];  // this lane's records
+  int                  lane;
+
+  __device__ __forceinline__ unsigned long long get(int j) const {  // j wave-uniform
+    const int          s = j >> 6;
+    unsigned long long x = v[0];
+#pragma unroll
+    for (int t = 1; t < R; t++) x = s == t ? v[t] : x;
+    const int l = j & 63;
+    const unsigned     lo = __builtin_amdgcn_readlane((int)(unsigned)x, l), hi = __builtin_amdgcn_readlane((int)(unsigned)(x >> 32), l);
+    return ((unsigned long long)hi << 32) | lo;
+  }
+  __device__ __forceinline__ void set(int j, unsigned long long x) {
+    const int s = j >> 6;
+    if (lane == (j & 63)) {
+#pragma unroll
+      for (int t = 0; t < R; t++)
+        if (s == t) v[t] = x;
+    }
+  }
+  __device__ __forceinline__ void swap(int i, int j) {
+    const unsigned long long a = get(i), b = get(j);
+    set(i, b);
+    set(j, a);
+  }
+  // smallest index in [from, to) whose record satisfies !(rec < pivot)   (rec compared on bits 63..16)
+  __device__ __forceinline__ int first_not_less(int from, int to, unsigned long long pivot) const {
+    const unsigned long long pk = pivot >> 16;
+#pragma unroll
+    for (int s = 0; s < R; s++) {
+      const int                idx = s * 64 + lane;
+      const unsigned long long m   = __ballot(idx >= from && idx < to && !((v[s] >> 16) < pk));
+      if (m) return s * 64 + (__ffsll((long long)m) - 1);
+    }
+    return to;
+  }
+  // largest index in [from, to) whose record satisfies !(pivot < rec)
+  __device__ __forceinline__ int last_not_greater(int from, int to, unsigned long long pivot) const {
+    const unsigned long long pk = pivot >> 16;
+#pragma unroll
+    for (int s = R - 1; s >= 0; s--) {
+      const int                idx = s * 64 + lane;
+      const unsigned long long m   = __ballot(idx >= from && idx < to && !(pk < (v[s] >> 16)));
+      if (m) return s * 64 + 63 - __clzll((long long)m);
+    }
+    return from - 1;
+  }
+  // records a .. b-1 move one place up (to a+1 .. b), then record a = x      (move_backward + store)
+  __device__ __forceinline__ void shift_up_insert(int a, int b, unsigned long long x) {
+    unsigned long long prev[R];
+#pragma unroll
+    for (int s = 0; s < R; s++) {
+      // value of record (s*64 + lane - 1)
+      const unsigned long long own   = v[s];
+      const unsigned long long below = s > 0 ? v[s - 1] : 0ull;
+      const unsigned           lo1 = (unsigned)__shfl_up((int)(unsigned)own, 1, 64), hi1 = (unsigned)__shfl_up((int)(unsigned)(own >> 32), 1, 64);
+      const unsigned           lo2 = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)below, 63),
+                     hi2           = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(below >> 32), 63);
+      prev[s] = lane == 0 ? (((unsigned long long)hi2 << 32) | lo2) : (((unsigned long long)hi1 << 32) | lo1);
+    }
+#pragma unroll
+    for (int s = 0; s < R; s++) {
+      const int idx = s * 64 + lane;
+      if (idx > a && idx <= b) v[s] = prev[s];
+      if (idx == a) v[s] = x;
+    }
+  }
+
+  // returns false if the depth limit was reached on a range > 16 (heap-sort path): caller falls back
+  __device__ __forceinline__ bool run(int n, int* stk) {  // stk: 3 x 64 ints in LDS (wave-uniform work list)
+    int lg = 0;
+    while ((1 << (lg + 1)) <= n) lg++;
+    int *sf = stk, *sl = stk + 64, *sd = stk + 128, sp = 0;
+    sf[0] = 0, sl[0] = n, sd[0] = 2 * lg, sp = 1;
+    while (sp > 0) {
+      --sp;
+      int first = sf[sp], last = sl[sp], depth = sd[sp];
+      while (last - first > 16) {
+        if (depth == 0) return false;
+        --depth;
+        // __move_median_to_first(first, first + 1, mid, last - 1)
+        const int                mid = first + (last - first) / 2;
+        const int                ia = first + 1, ib = mid, ic = last - 1;
+        const unsigned long long A = get(ia) >> 16, B = get(ib) >> 16, C = get(ic) >> 16;
+        if (A < B) {
+          if (B < C)
+            swap(first, ib);
+          else if (A < C)
+            swap(first, ic);
+          else
+            swap(first, ia);
+        } else if (A < C)
+          swap(first, ia);
+        else if (B < C)
+          swap(first, ic);
+        else
+          swap(first, ib);
+        // __unguarded_partition(first + 1, last, first)
+        const unsigned long long pivot = get(first);
+        int                      lo = first + 1, hi = last;
+        while (true) {
+          lo = first_not_less(lo, last, pivot);        // while (comp(*lo, pivot)) ++lo;
+          hi = last_not_greater(first, hi, pivot);     // --hi; while (comp(pivot, *hi)) --hi;
+          if (!(lo < hi)) break;
+          swap(lo, hi);
+          ++lo;
+        }
+        const int cut = lo;
+        sf[sp] = cut, sl[sp] = last, sd[sp] = depth;
+        sp++;
+        last = cut;
+      }
+    }
+    // __final_insertion_sort: guarded insertion on the first 16 (or all), unguarded linear inserts after
+    const int guarded = n > 16 ? 16 : n;
+    for (int i = 1; i < n; i++) {
+      const unsigned long long val = get(i);
+      if (i < guarded && (val >> 16) < (get(0) >> 16)) {
+        shift_up_insert(0, i, val);  // move_backward(first, i, i + 1); *first = val
+      } else {
+        // __unguarded_linear_insert(i): position after the last record that is not greater than val
+        const int p = last_not_greater(0, i, val);
+        if (p + 1 < i) shift_up_insert(p + 1, i, val);
+      }
+    }
+    return true;
+  }
+};
+
+template <int R>
+__device__ __forceinline__ bool ot_wave_sort_r(unsigned long long* buf, int n, int* stk) {
+  const int   lane = threadIdx.x & 63;
+  WaveSort<R> w;
+  w.lane = lane;
+#pragma unroll
+  for (int s = 0; s < R; s++) w.v[s] = (s * 64 + lane) < n ? buf[s * 64 + lane] : ~0ull;
+  if (!w.run(n, stk)) return false;
+#pragma unroll
+  for (int s = 0; s < R; s++)
+    if (s * 64 + lane < n) buf[s * 64 + lane] = w.v[s];
+  return true;
+}
+
+__device__ inline void ot_wave_sort(unsigned long long* buf, int n, int* stk) {  // called by ONE full wave; buf in LDS or global
+  bool done = false;
+  if (n <= 64)
+    done = ot_wave_sort_r<1>(buf, n, stk);
+  else if (n <= 128)
+    done = ot_wave_sort_r<2>(buf, n, stk);
+  else if (n <= 256)
+    done = ot_wave_sort_r<4>(buf, n, stk);
+  if (!done && (threadIdx.x & 63) == 0) ot_std_sort(buf, n, -1, stk);  // large inputs / depth-limit case: the serial re-enactment
+}
+
 struct DevCtx {
   int   tid, nt;
-  int*  lds;  // >= 4 * 16 + 4 ints of LDS scratch (per-wave totals)
+  int*  lds;  // >= 80 ints of LDS scratch (per-wave totals) followed by 192 ints of sort work list
   __device__ void sync() { __syncthreads(); }
   __device__ Int4 scan4(const Int4& v, Int4* total) {
     const int lane = tid & 63, wave = tid >> 6, nw = (nt + 63) >> 6;
@@ -264,6 +442,9 @@ struct DevCtx {
 #pragma unroll
     for (int k = 0; k < 4; k++) ex.v[k] = base.v[k] + inc.v[k] - v.v[k];
     return ex;
+  }
+  __device__ void sort(unsigned long long* buf, int n) {
+    if (tid < 64) ot_wave_sort(buf, n, lds + 80);
   }
   __device__ int min_reduce(int v) {
     const int lane = tid & 63, wave = tid >> 6, nw = (nt + 63) >> 6;
@@ -325,6 +506,7 @@ struct OtState {
 
 template <class CTX>
 OT_HD inline void ot_divide_step(CTX& c, const OtArgs& a, OtState& s, int nD, bool mode_ordered) {
+  if (a.dbgT && c.tid == 0) a.dbgT[2] += 1;
   const int n = a.n;
   // -- A: classify every point of a flagged node into its child quadrant, prefix-count per quadrant
   int lo, hi;
@@ -485,6 +667,7 @@ OT_HD inline void ot_divide_step(CTX& c, const OtArgs& a, OtState& s, int nD, bo
 // ------------------------------------------------------------------------------------------------
 template <class CTX>
 OT_HD inline void ot_distribute(CTX& c, const OtArgs& a) {
+  const long long tStart = OT_CLOCK();
   const int n = a.n;
   if (n <= 0) {
     if (c.tid == 0) *a.outCount = 0;
@@ -559,8 +742,10 @@ OT_HD inline void ot_distribute(CTX& c, const OtArgs& a) {
                          (unsigned long long)(unsigned)j;
         }
         c.sync();
-        if (c.tid == 0) ot_std_sort(a.sortbuf, V);
+        const long long t0 = OT_CLOCK();
+        c.sort(a.sortbuf, V);
         c.sync();
+        if (a.dbgT && c.tid == 0) a.dbgT[0] += OT_CLOCK() - t0, a.dbgT[3] += 1;
         // processed from the back of the sorted vector (:686)
         for (int k = c.tid; k < V; k += c.nt) {
           const int node = s.v[(int)(a.sortbuf[V - 1 - k] & 0xffffu)];
@@ -584,6 +769,7 @@ OT_HD inline void ot_distribute(CTX& c, const OtArgs& a) {
     a.outKp[i] = best;
   }
   if (c.tid == 0) *a.outCount = s.nNodes;
+  if (a.dbgT && c.tid == 0) a.dbgT[1] += OT_CLOCK() - tStart;
   c.sync();
 }
 

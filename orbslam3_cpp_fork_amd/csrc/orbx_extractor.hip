@@ -96,6 +96,7 @@ struct orbx_extractor {
   DevBuf<uint8_t> dPyr, dBlur, dQv, dStage, dDescOut;
   DevBuf<int2>    dXtab, dYtab;
   DevBuf<int4>    dCellDesc;
+  DevBuf<long long> dDbgT;
   DevBuf<int>     dCellOrder, dCellSlot, dCellCount, dOrdA, dOrdB, dNodeOfA, dNodeOfB, dP, dD, dDIndex, dNCh, dPushOff, dMultiOff, dKeptRank, dVA,
       dVB, dCandCount, dLvlCount, dOutIdx, dCounts;
   DevBuf<uint32_t>           dSlots, dCand, dLvlKp;
@@ -326,6 +327,13 @@ int orbx_extractor::run(const uint8_t* d_imgs, int B, int rows, int cols, size_t
   if (rc) return rc;
   const FrameGeom& g = geom;
   Bufs             b = bufs;
+  if (getenv("ORBX_DBG_OCT")) {
+    if (dDbgT.ensure((size_t)B * g.nlevels * 4)) return -3;
+    HIP_TRY(hipMemsetAsync(dDbgT.p, 0, (size_t)B * g.nlevels * 4 * sizeof(long long), s));
+    b.dbgT = dDbgT.p;
+  } else {
+    b.dbgT = nullptr;
+  }
   b.img0            = d_imgs;
   b.img0FrameStride = (long long)frameStride;
   b.img0Pitch       = (int)step;
@@ -642,6 +650,7 @@ int orbx_debug_octree_device(orbx_t* h, const uint32_t* cand, int n, int W, int 
   if (n > 0) HIP_TRY(hipMemcpy(dc.p, cand, (size_t)n * 4, hipMemcpyHostToDevice));
   OtArgs a;
   memset(&a, 0, sizeof(a));
+  a.dbgT = nullptr;
   a.cand = dc.p, a.n = n, a.W = W, a.H = H, a.N = N, a.nIni = nIni, a.hX = (float)W / nIni, a.maxNodes = maxNodes;
   a.ordA = ordA.p, a.ordB = ordB.p, a.nodeOfA = nA.p, a.nodeOfB = nB.p, a.P = P.p, a.qv = qv.p, a.nodesA = nodesA.p, a.nodesB = nodesB.p;
   a.startCnt = sc.p, a.endCnt = ec.p, a.D = D.p, a.dIndex = dI.p, a.nCh = nCh.p, a.pushOff = pO.p, a.multiOff = mO.p, a.keptRank = kR.p;
@@ -676,6 +685,16 @@ int orbx_debug_calib_read(orbx_t* h, long long nbytes, int width) {
   HIP_TRY(hipStreamSynchronize(h->stream));
   buf.release(), sink.release();
   return 0;
+}
+
+// Tuning hook (ORBX_DBG_OCT=1): per (frame, level) {sort cycles, total cycles, division steps, sorts} of the last batch.
+int orbx_debug_octree_times(orbx_t* h, long long* out, int cap) {
+  if (!h || !h->dDbgT.p) return -2;
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipDeviceSynchronize());
+  const int n = std::min(cap, h->lastB * h->nlevels * 4);
+  HIP_TRY(hipMemcpy(out, h->dDbgT.p, (size_t)n * sizeof(long long), hipMemcpyDeviceToHost));
+  return n;
 }
 
 void orbx_set_profiling(orbx_t* h, int enable) {

@@ -30,6 +30,7 @@ struct Bufs {
   const uint8_t* img0;
   long long      img0FrameStride;
   int            img0Pitch;
+  long long*     dbgT;  // optional quadtree timing stamps [frame][level][4] (ORBX_DBG_OCT=1)
   uint8_t*       pyr;   // [B][pyrBytes]   levels >= 1
   uint8_t*       blur;  // [B][blurBytes]  all levels
   const int2*    xtab;  // resize tables: .x = source index, .y = a0 | a1 << 16 (Q11)
@@ -495,7 +496,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(Bufs b, FrameGeom g, int ini
 // DistributeOctTree: one workgroup per (frame, level).  First gathers the per-cell candidate slots into
 // the feed order of the reference (cells row-major, row-major inside a cell), then runs octree_core.h.
 // ------------------------------------------------------------------------------------------------
-constexpr int kOctThreads  = 256;  // 124 VGPRs -> 4 waves/SIMD: 256-thread workgroups keep 4 (not 2) resident per CU
+constexpr int kOctThreads  = 64;   // one wave per (frame, level): barriers degenerate to wave syncs and 16 problems are resident per CU
 constexpr int kOctLdsSort  = 2048;
 
 __device__ __forceinline__ void octree_args(const Bufs& b, const FrameGeom& g, int f, int level, OtArgs* a) {
@@ -516,10 +517,11 @@ __device__ __forceinline__ void octree_args(const Bufs& b, const FrameGeom& g, i
   a->keptRank = b.keptRank + no, a->vA = b.vA + no, a->vB = b.vB + no, a->sortbuf = b.sortbuf + no;
   a->outKp    = b.lvlKp + (long long)f * g.totalKp + L.kpBase;
   a->outCount = b.lvlCount + (long long)f * g.nlevels + level;
+  a->dbgT     = b.dbgT ? b.dbgT + ((long long)f * g.nlevels + level) * 4 : nullptr;
 }
 
 __global__ __launch_bounds__(kOctThreads) void k_octree(Bufs b, FrameGeom g) {
-  __shared__ int                scratch[80];
+  __shared__ int                scratch[80 + 192];
   __shared__ unsigned long long ldsSort[kOctLdsSort];
   const int                     level = blockIdx.x, f = blockIdx.y;
   const LevelGeom&              L = g.lv[level];
@@ -560,7 +562,7 @@ __global__ __launch_bounds__(kOctThreads) void k_octree(Bufs b, FrameGeom g) {
 
 // stand-alone quadtree on caller-supplied candidates (parity hook)
 __global__ __launch_bounds__(kOctThreads) void k_octree_only(OtArgs a) {
-  __shared__ int scratch[80];
+  __shared__ int scratch[80 + 192];
   DevCtx         c;
   c.tid = threadIdx.x, c.nt = kOctThreads, c.lds = scratch;
   ot_distribute(c, a);

@@ -1,0 +1,19 @@
+import os, sys, ctypes as C, numpy as np, torch
+os.environ["ORBX_DBG_OCT"] = "1"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from orbslam3_cpp_fork_amd import synth, _lib
+from orbslam3_cpp_fork_amd.extractor import ORBextractor
+B, rows, cols = 64, 480, 640
+fr = synth.make_stream(rows, cols, B)
+ts = torch.cuda.Stream(); torch.cuda.set_stream(ts)
+d = torch.from_numpy(fr).cuda()
+ex = ORBextractor(1000); cap = ex.max_keypoints(rows, cols)
+kps = torch.zeros((B, cap, 7), device="cuda"); desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda"); cnt = torch.zeros((B, 2), dtype=torch.int32, device="cuda")
+for _ in range(2):
+    ex.extract_batch_device(d, B, rows, cols, cols, rows * cols, kps, desc, cnt, cap, (0, 1000), stream=ts.cuda_stream)
+torch.cuda.synchronize()
+out = np.zeros(B * 8 * 4, np.int64)
+n = _lib.lib().orbx_debug_octree_times(ex._h, out.ctypes.data_as(C.c_void_p), len(out))
+t = out[:n].reshape(B, 8, 4)
+for l in range(8):
+    print("level %d: sort cyc %8.0f  total cyc %8.0f  steps %.1f sorts %.1f  cands %s" % (l, t[:, l, 0].mean(), t[:, l, 1].mean(), t[:, l, 2].mean(), t[:, l, 3].mean(), ""))
