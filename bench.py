@@ -101,11 +101,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    local_rank %= max(torch.cuda.device_count(), 1)  # rehearsals with more ranks than GPUs share a device
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # "nccl" IS RCCL on ROCm.  ORBX_DIST_BACKEND=gloo lets the multi-rank control flow be rehearsed on a one-GPU box
+    # (RCCL refuses two ranks on one device); the gather then stages through host memory.
+    backend = os.environ.get("ORBX_DIST_BACKEND", "nccl")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from orbslam3_cpp_fork_amd import shard, synth
     from orbslam3_cpp_fork_amd.extractor import ORBextractor
@@ -138,7 +145,7 @@ def main():
             self.tstream = torch.cuda.Stream(device=dev)  # explicit, non-default: NULL would select the handle's private stream
             self.stream = self.tstream.cuda_stream
             assert self.stream
-            self.gather = shard.RecordGather(B, self.cap, dev, world, rank) if world > 1 else None
+            self.gather = shard.RecordGather(B, self.cap, dev, world, rank, host_staged=(backend != "nccl")) if world > 1 else None
             self.pending = None
             self.match_ev = []
 
@@ -198,7 +205,7 @@ def main():
     for ln in lanes:
         ln.ex.set_profiling(False)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     d_cnt, d_nm = lanes[0].d_cnt, lanes[0].d_nm
@@ -212,7 +219,7 @@ def main():
         ab = algorithmic_bytes(rows, cols, nfeat)
         # dominant kernel class = the stage with the largest mean HIP-event duration in the timed region
         kernels = {"pyramid": "k_resize_level", "fast": "k_fast_cells", "octree": "k_octree", "blur": "k_blur_levels", "orient_describe": "k_orient_describe",
-                   "match": "k_group_topk+k_group_resolve"}
+                   "match": "k_bf_topk+k_group_resolve"}
         # matcher: descriptors of both frames read once + one match index per query ((nq + nt) * 32 + nq * 4)
         ab["match"] = int(2 * cnt[:, 0].mean() * 32 + cnt[:, 0].mean() * 4)
         dom = max(kernels, key=lambda k: stage[k])

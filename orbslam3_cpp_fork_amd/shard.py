@@ -31,13 +31,15 @@ def record_bytes(B, cap):
 class RecordGather:
     """Packs (counts, keypoints, descriptors) of one step into one byte tensor and gathers it on rank 0."""
 
-    def __init__(self, B, cap, device, world, rank, dst=0):
+    def __init__(self, B, cap, device, world, rank, dst=0, host_staged=False):
         import torch
 
         self.B, self.cap, self.world, self.rank, self.dst = B, cap, world, rank, dst
         self.nbytes = record_bytes(B, cap)
+        self.host_staged = host_staged  # backends without device collectives (gloo rehearsal): gather through host memory
         self.send = torch.empty(self.nbytes, dtype=torch.uint8, device=device)
-        self.recv = [torch.empty(self.nbytes, dtype=torch.uint8, device=device) for _ in range(world)] if rank == dst else None
+        rdev = "cpu" if host_staged else device
+        self.recv = [torch.empty(self.nbytes, dtype=torch.uint8, device=rdev) for _ in range(world)] if rank == dst else None
         self._o1 = B * 2 * 4
         self._o2 = self._o1 + B * cap * 28
 
@@ -55,7 +57,8 @@ class RecordGather:
         import torch.distributed as dist
 
         self.pack(d_kps, d_desc, d_cnt)
-        work = dist.gather(self.send, self.recv, dst=self.dst, async_op=async_op)
+        send = self.send.cpu() if self.host_staged else self.send
+        work = dist.gather(send, self.recv, dst=self.dst, async_op=async_op)
         return work if async_op else self.recv
 
     def unpack(self, buf):
