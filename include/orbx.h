@@ -72,6 +72,16 @@ int orbx_extract_batch_device(orbx_t* h, const uint8_t* d_imgs, int nframes, int
  * dst may be NULL to query the size. */
 int orbx_pyramid_level(orbx_t* h, int frame, int level, uint8_t* dst, size_t dst_step, int* rows, int* cols);
 
+/* Frame::ComputeStereoMatches (reference src/Frame.cc:944-1113) on the device-resident pyramids of two extractors
+ * that have just run orbx_extract on the left / right image (same size, same device): row-band candidate search,
+ * best Hamming below TH_HIGH, 11 x 11 SAD over +-5 px on the keypoint's pyramid level, parabola sub-pixel fit,
+ * median-distance cut.  Host pointers, synchronous.  Writes mvuRight / mvDepth (-1 = no match); mb, mbf = Frame::mb,
+ * Frame::mbf.  Returns the number of stereo matches kept.  With this call the caller no longer needs
+ * orbx_pyramid_level() copies of mvImagePyramid for the stereo case. */
+int orbx_stereo_matches(orbx_t* left, orbx_t* right, const orbx_keypoint_t* kps_left, const uint8_t* desc_left, int n_left,
+                        const orbx_keypoint_t* kps_right, const uint8_t* desc_right, int n_right, float mb, float mbf, float* u_right,
+                        float* depth);
+
 /* Stage timing with HIP events recorded on the launch stream between the kernels of every batch:
  * enable (resets the record), run batches, then read the mean milliseconds per stage over the batches
  * recorded since (at most the last 32); returns the number of batches averaged.  Stages: 0 pyramid

@@ -59,6 +59,7 @@ def lib():
         L.orao_libm_sincos_deg.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.orao_sincos_port_mismatches.restype = C.c_long
         L.orao_sincos_port_mismatches.argtypes = [C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_void_p, i32p]
+        L.orao_stereo_matches.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
         L.orao_hamming.argtypes = [C.c_void_p, C.c_void_p]
         L.orao_three_maxima.argtypes = [C.c_void_p, C.c_int, i32p, i32p, i32p]
         L.orao_match_groups.argtypes = (
@@ -264,3 +265,14 @@ def match_window(d1, kp1, d2, kp2, prev_matched, bounds, window=100, th=50, rati
     m12 = np.zeros(len(kp1), np.int32)
     n = lib().orao_match_window(_p(d1), _p(kp1), len(kp1), _p(d2), _p(kp2), len(kp2), _p(pm), *[float(b) for b in bounds], window, th, ratio, int(check_ori), _p(m12))
     return n, m12, pm
+
+
+def stereo_matches(ex_left, ex_right, kl, dl, kr, dr, mb, mbf):
+    """Frame::ComputeStereoMatches on the pyramids of the last extract of the two OracleExtractor objects."""
+    kl = np.ascontiguousarray(kl, KP_DTYPE)
+    kr = np.ascontiguousarray(kr, KP_DTYPE)
+    dl = np.ascontiguousarray(dl, np.uint8)
+    dr = np.ascontiguousarray(dr, np.uint8)
+    u, d = np.zeros(len(kl), np.float32), np.zeros(len(kl), np.float32)
+    n = lib().orao_stereo_matches(ex_left._h, ex_right._h, _p(kl), _p(dl), len(kl), _p(kr), _p(dr), len(kr), mb, mbf, _p(u), _p(d))
+    return n, u, d

@@ -841,6 +841,109 @@ long orao_sincos_port_mismatches(uint32_t bits_lo, uint32_t bits_hi, int fma_var
   return bad;
 }
 
+// Frame::ComputeStereoMatches (src/Frame.cc:944-1113)
+int orao_stereo_matches(const orao_extractor_t* L, const orao_extractor_t* R, const orao_keypoint_t* mvKeys, const uint8_t* mDescriptors,
+                        int N, const orao_keypoint_t* mvKeysRight, const uint8_t* mDescriptorsRight, int Nr, float mb, float mbf,
+                        float* mvuRight, float* mvDepth) {
+  for (int i = 0; i < N; i++) mvuRight[i] = -1.0f, mvDepth[i] = -1.0f;
+  const int TH_HIGH = 100, TH_LOW = 50;
+  const int thOrbDist = (TH_HIGH + TH_LOW) / 2;
+  const int nRows = L->pyramid[0].h;
+  std::vector<std::vector<size_t>> vRowIndices(nRows, std::vector<size_t>());
+  for (int iR = 0; iR < Nr; iR++) {
+    const orao_keypoint_t& kp  = mvKeysRight[iR];
+    const float            kpY = kp.y;
+    const float            r   = 2.0f * R->mvScaleFactor[kp.octave];
+    const int              maxr = (int)std::ceil(kpY + r);
+    const int              minr = (int)std::floor(kpY - r);
+    for (int yi = minr; yi <= maxr; yi++)
+      if (yi >= 0 && yi < nRows) vRowIndices[yi].push_back(iR);  // (out-of-range rows are UB in the reference; they cannot occur: keypoints stay 19 px inside)
+  }
+  const float minZ = mb, minD = 0, maxD = mbf / minZ;
+  std::vector<std::pair<int, int>> vDistIdx;
+  for (int iL = 0; iL < N; iL++) {
+    const orao_keypoint_t& kpL    = mvKeys[iL];
+    const int              levelL = kpL.octave;
+    const float            vL = kpL.y, uL = kpL.x;
+    const std::vector<size_t>& vCandidates = vRowIndices[(size_t)vL];
+    if (vCandidates.empty()) continue;
+    const float minU = uL - maxD, maxU = uL - minD;
+    if (maxU < 0) continue;
+    int    bestDist = TH_HIGH;
+    size_t bestIdxR = 0;
+    const uint8_t* dL = mDescriptors + (size_t)iL * 32;
+    for (size_t iC = 0; iC < vCandidates.size(); iC++) {
+      const size_t           iR  = vCandidates[iC];
+      const orao_keypoint_t& kpR = mvKeysRight[iR];
+      if (kpR.octave < levelL - 1 || kpR.octave > levelL + 1) continue;
+      const float uR = kpR.x;
+      if (uR >= minU && uR <= maxU) {
+        const int dist = orao_hamming(dL, mDescriptorsRight + iR * 32);
+        if (dist < bestDist) {
+          bestDist = dist;
+          bestIdxR = iR;
+        }
+      }
+    }
+    if (bestDist < thOrbDist) {
+      const float uR0         = mvKeysRight[bestIdxR].x;
+      const float scaleFactor = L->mvInvScaleFactor[kpL.octave];
+      const float scaleduL    = std::round(kpL.x * scaleFactor);
+      const float scaledvL    = std::round(kpL.y * scaleFactor);
+      const float scaleduR0   = std::round(uR0 * scaleFactor);
+      const int   w = 5;
+      const Img&  imL = L->pyramid[kpL.octave];
+      const Img&  imR = R->pyramid[kpL.octave];
+      int         bestDistS = INT_MAX, bestincR = 0;
+      const int   Ls = 5;
+      float       vDists[2 * 5 + 1];
+      const float iniu = scaleduR0 + Ls - w;
+      const float endu = scaleduR0 + Ls + w + 1;
+      if (iniu < 0 || endu >= imR.w) continue;
+      const int y0 = (int)(scaledvL - w), xl0 = (int)(scaleduL - w);
+      for (int incR = -Ls; incR <= +Ls; incR++) {
+        const int xr0 = (int)(scaleduR0 + incR - w);
+        double    acc = 0;  // cv::norm(IL, IR, NORM_L1)
+        for (int yy = 0; yy < 2 * w + 1; yy++)
+          for (int xx = 0; xx < 2 * w + 1; xx++) acc += std::abs((int)imL.row(y0 + yy)[xl0 + xx] - (int)imR.row(y0 + yy)[xr0 + xx]);
+        float dist = (float)acc;
+        if (dist < bestDistS) {
+          bestDistS = (int)dist;
+          bestincR  = incR;
+        }
+        vDists[Ls + incR] = dist;
+      }
+      if (bestincR == -Ls || bestincR == Ls) continue;
+      const float dist1 = vDists[Ls + bestincR - 1], dist2 = vDists[Ls + bestincR], dist3 = vDists[Ls + bestincR + 1];
+      const float deltaR = (dist1 - dist3) / (2.0f * (dist1 + dist3 - 2.0f * dist2));
+      if (deltaR < -1 || deltaR > 1) continue;
+      float bestuR    = L->mvScaleFactor[kpL.octave] * ((float)scaleduR0 + (float)bestincR + deltaR);
+      float disparity = (uL - bestuR);
+      if (disparity >= minD && disparity < maxD) {
+        if (disparity <= 0) {
+          disparity = 0.01;
+          bestuR    = uL - 0.01;
+        }
+        mvDepth[iL]  = mbf / disparity;
+        mvuRight[iL] = bestuR;
+        vDistIdx.push_back(std::pair<int, int>(bestDistS, iL));
+      }
+    }
+  }
+  if (vDistIdx.empty()) return 0;  // the reference indexes an empty vector here
+  std::sort(vDistIdx.begin(), vDistIdx.end());
+  const float median = vDistIdx[vDistIdx.size() / 2].first;
+  const float thDist = 1.5f * 1.4f * median;
+  int         kept   = (int)vDistIdx.size();
+  for (int i = (int)vDistIdx.size() - 1; i >= 0; i--) {
+    if (vDistIdx[i].first < thDist) break;
+    mvuRight[vDistIdx[i].second] = -1;
+    mvDepth[vDistIdx[i].second]  = -1;
+    kept--;
+  }
+  return kept;
+}
+
 // ------------------------------------------------------------------------------------------------
 // ORBmatcher
 // ------------------------------------------------------------------------------------------------

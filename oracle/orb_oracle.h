@@ -78,6 +78,13 @@ void orao_libm_sincos_deg(const float* deg, int n, float* cos_out, float* sin_ou
 long orao_sincos_port_mismatches(uint32_t bits_lo, uint32_t bits_hi, int fma_variant, int nthreads,
                                  uint32_t* first_bad /* up to 16 entries */, int* n_first_bad);
 
+/* Frame::ComputeStereoMatches (src/Frame.cc:944-1113) on the pyramids of the last extract of `left` / `right`:
+ * row-band candidates, best Hamming below TH_HIGH, 11x11 SAD over +-5 px on the keypoint's pyramid level, parabola
+ * sub-pixel fit, median-distance cut.  Writes mvuRight / mvDepth (-1 = no match).  Returns the number of matches kept. */
+int orao_stereo_matches(const orao_extractor_t* left, const orao_extractor_t* right, const orao_keypoint_t* kl, const uint8_t* dl,
+                        int nl, const orao_keypoint_t* kr, const uint8_t* dr, int nr, float mb, float mbf, float* u_right,
+                        float* depth);
+
 /* ---- matcher ---- */
 /* ORBmatcher::DescriptorDistance (src/ORBmatcher.cc:2075-2089) */
 int orao_hamming(const uint8_t* a32, const uint8_t* b32);

@@ -668,6 +668,62 @@ int orbx_debug_octree_device(orbx_t* h, const uint32_t* cand, int n, int W, int 
   return 0;
 }
 
+// Frame::ComputeStereoMatches (reference src/Frame.cc:944-1113).  Both handles must have extracted an image of the same
+// size with their single-frame orbx_extract (the pyramids of that call are still resident on the device).
+int orbx_stereo_matches(orbx_t* left, orbx_t* right, const orbx_keypoint_t* kl, const uint8_t* dl, int nl, const orbx_keypoint_t* kr,
+                        const uint8_t* dr, int nr, float mb, float mbf, float* u_right, float* depth) {
+  using namespace orbx;
+  if (!left || !right || nl < 0 || nr < 0 || (nl > 0 && (!kl || !dl || !u_right || !depth)) || (nr > 0 && (!kr || !dr)) || !(mb > 0.f)) {
+    g_err = "orbx_stereo_matches: bad arguments";
+    return -2;
+  }
+  if (!left->haveGeom || !right->haveGeom || left->lastB < 1 || right->lastB < 1 || left->geom.rows != right->geom.rows ||
+      left->geom.cols != right->geom.cols || left->nlevels != right->nlevels || left->device != right->device) {
+    g_err = "orbx_stereo_matches: both extractors must hold the pyramid of a same-sized image on the same device";
+    return -2;
+  }
+  if (nr > 65535) {
+    g_err = "orbx_stereo_matches: more than 65535 right keypoints";
+    return -2;
+  }
+  if (nl == 0) return 0;
+  HIP_TRY(hipSetDevice(left->device));
+  HIP_TRY(hipStreamSynchronize(right->stream));
+  hipStream_t      s = left->stream;
+  DevBuf<KpRec>    dkl, dkr;
+  DevBuf<uint8_t>  ddl, ddr;
+  DevBuf<float>    du, dd;
+  DevBuf<int>      dsad, dkept;
+  if (dkl.ensure(nl) || dkr.ensure(nr + 1) || ddl.ensure((size_t)nl * 32) || ddr.ensure((size_t)nr * 32 + 32) || du.ensure(nl) || dd.ensure(nl) ||
+      dsad.ensure(nl) || dkept.ensure(1))
+    return -3;
+  HIP_TRY(hipMemcpyAsync(dkl.p, kl, (size_t)nl * sizeof(KpRec), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(ddl.p, dl, (size_t)nl * 32, hipMemcpyHostToDevice, s));
+  if (nr) {
+    HIP_TRY(hipMemcpyAsync(dkr.p, kr, (size_t)nr * sizeof(KpRec), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(ddr.p, dr, (size_t)nr * 32, hipMemcpyHostToDevice, s));
+  }
+  StereoArgs a;
+  a.kl = dkl.p, a.kr = dkr.p, a.dl = ddl.p, a.dr = ddr.p, a.nl = nl, a.nr = nr, a.nrows = left->geom.rows, a.mb = mb, a.mbf = mbf;
+  a.pyrL0 = left->bufs.img0, a.pyrR0 = right->bufs.img0, a.pitch0 = left->bufs.img0Pitch;
+  if (right->bufs.img0Pitch != left->bufs.img0Pitch) {
+    g_err = "orbx_stereo_matches: level-0 pitches differ";
+    return -2;
+  }
+  a.pyrL = left->bufs.pyr, a.pyrR = right->bufs.pyr;
+  a.uRight = du.p, a.depth = dd.p, a.sad = dsad.p;
+  hipLaunchKernelGGL(k_stereo_match, dim3((nl + 3) / 4), dim3(256), 0, s, a, left->geom);
+  hipLaunchKernelGGL(k_stereo_cut, dim3(1), dim3(256), 0, s, a, dkept.p);
+  HIP_TRY(hipGetLastError());
+  int kept = 0;
+  HIP_TRY(hipMemcpyAsync(u_right, du.p, (size_t)nl * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(depth, dd.p, (size_t)nl * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(&kept, dkept.p, 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  dkl.release(), dkr.release(), ddl.release(), ddr.release(), du.release(), dd.release(), dsad.release(), dkept.release();
+  return kept;
+}
+
 // PMC calibration hook (see k_calib_read): reads `nbytes` of a scratch buffer with `width` bytes per lane per load.
 int orbx_debug_calib_read(orbx_t* h, long long nbytes, int width) {
   if (!h || nbytes <= 0 || (width != 1 && width != 4 && width != 16)) return -2;

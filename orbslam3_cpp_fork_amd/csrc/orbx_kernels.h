@@ -887,6 +887,175 @@ __global__ __launch_bounds__(256) void k_orient_describe(Bufs b, FrameGeom g, co
 }
 
 // ------------------------------------------------------------------------------------------------
+// Frame::ComputeStereoMatches (reference src/Frame.cc:944-1113) on the two device-resident pyramids.
+// One wave per left keypoint: (1) the row-band candidate scan -- the reference's vRowIndices[vL] holds right keypoint
+// iR iff floor(yR - r) <= (int)vL <= ceil(yR + r), r = 2 * scale[octave R], lists in increasing iR -- as a strided scan
+// over all right keypoints with the same octave and u-range filters, best Hamming = wave-min of (dist << 16 | iR)
+// (strict '<' in increasing iR = smallest iR among equal distances); (2) 11 x 11 SAD over the 11 shifts on the
+// keypoint's pyramid level (integer sums, exact), parabola fit and depth in the reference's float sequence by lane 0.
+// k_stereo_cut then applies the median-distance cut (:1101-1112): the median is the (n/2)-th smallest SAD distance.
+// ------------------------------------------------------------------------------------------------
+struct StereoArgs {
+  const KpRec *  kl, *kr;
+  const uint8_t *dl, *dr;
+  int            nl, nr, nrows;
+  float          mb, mbf;
+  const uint8_t *pyrL0, *pyrR0;  // level-0 images (row pitch pitch0)
+  int            pitch0;
+  const uint8_t *pyrL, *pyrR;    // levels >= 1 (frame 0 of each handle)
+  float *        uRight, *depth;
+  int*           sad;            // best SAD distance per left keypoint, -1 = not a match
+};
+
+__global__ __launch_bounds__(256) void k_stereo_match(StereoArgs a, FrameGeom g) {
+  const int iL = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (iL >= a.nl) return;
+  const KpRec kpL    = a.kl[iL];
+  const int   levelL = kpL.octave;
+  const float vL = kpL.y, uL = kpL.x;
+  const float minD = 0.f, maxD = a.mbf / a.mb;
+  const float minU = uL - maxD, maxU = uL - minD;
+  int         sadOut = -1;
+  float       uOut = -1.0f, dOut = -1.0f;
+  const int   rowL = (int)vL;  // vRowIndices[vL]
+  uint32_t    best = 0xffffffffu;
+  if (!(maxU < 0)) {
+    const uint4 a0 = *reinterpret_cast<const uint4*>(a.dl + (size_t)iL * 32), a1 = *reinterpret_cast<const uint4*>(a.dl + (size_t)iL * 32 + 16);
+    for (int iR = lane; iR < a.nr; iR += 64) {
+      const KpRec kpR  = a.kr[iR];
+      const float r    = 2.0f * g.lv[kpR.octave].scale;
+      const int   maxr = (int)ceilf(kpR.y + r), minr = (int)floorf(kpR.y - r);
+      if (rowL < minr || rowL > maxr || rowL < 0 || rowL >= a.nrows) continue;
+      if (kpR.octave < levelL - 1 || kpR.octave > levelL + 1) continue;
+      if (kpR.x >= minU && kpR.x <= maxU) {
+        const uint4 b0 = *reinterpret_cast<const uint4*>(a.dr + (size_t)iR * 32), b1 = *reinterpret_cast<const uint4*>(a.dr + (size_t)iR * 32 + 16);
+        const int   d  = __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) + __popc(a1.x ^ b1.x) +
+                      __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
+        best = min(best, ((uint32_t)d << 16) | (uint32_t)iR);
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) best = min(best, (uint32_t)__shfl_xor((int)best, off, 64));
+  }
+  const int bestDist = best == 0xffffffffu ? 100 : (int)(best >> 16);
+  if (bestDist < 100 && bestDist < (100 + 50) / 2) {  // < TH_HIGH (strict update from TH_HIGH) and < thOrbDist
+    const int   bestIdxR    = (int)(best & 0xffffu);
+    const float uR0         = a.kr[bestIdxR].x;
+    const float scaleFactor = 1.0f / g.lv[levelL].scale;  // mvInvScaleFactor (src/ORBextractor.cc:416)
+    const float scaleduL = roundf(kpL.x * scaleFactor), scaledvL = roundf(kpL.y * scaleFactor), scaleduR0 = roundf(uR0 * scaleFactor);
+    const int   w = 5, Ls = 5;
+    const float iniu = scaleduR0 + Ls - w, endu = scaleduR0 + Ls + w + 1;
+    if (!(iniu < 0 || endu >= g.lv[levelL].w)) {
+      const uint8_t *imL, *imR;
+      int            pitch;
+      if (levelL == 0) {
+        imL = a.pyrL0, imR = a.pyrR0, pitch = a.pitch0;
+      } else {
+        imL = a.pyrL + g.lv[levelL].pyrOff, imR = a.pyrR + g.lv[levelL].pyrOff, pitch = g.lv[levelL].pitch;
+      }
+      const int y0 = (int)(scaledvL - w), xl0 = (int)(scaleduL - w), xr0 = (int)(scaleduR0 - w);
+      int       acc[11];
+#pragma unroll
+      for (int k = 0; k < 11; k++) acc[k] = 0;
+      for (int p = lane; p < 121; p += 64) {
+        const int yy = p / 11, xx = p - yy * 11;
+        const int vl = imL[(long long)(y0 + yy) * pitch + xl0 + xx];
+        const uint8_t* rr = imR + (long long)(y0 + yy) * pitch + xr0 + xx;
+#pragma unroll
+        for (int k = 0; k < 11; k++) acc[k] += abs(vl - (int)rr[k - 5]);
+      }
+#pragma unroll
+      for (int k = 0; k < 11; k++)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc[k] += __shfl_xor(acc[k], off, 64);
+      int   bestS = 0x7fffffff, bestinc = 0;
+      float vDists[11];
+#pragma unroll
+      for (int k = 0; k < 11; k++) {
+        const float dist = (float)acc[k];
+        if (dist < (float)bestS) {
+          bestS   = (int)dist;
+          bestinc = k - 5;
+        }
+        vDists[k] = dist;
+      }
+      if (!(bestinc == -Ls || bestinc == Ls)) {
+        float dist1 = 0.f, dist2 = 0.f, dist3 = 0.f;
+#pragma unroll
+        for (int k = 1; k < 10; k++)
+          if (k - 5 == bestinc) dist1 = vDists[k - 1], dist2 = vDists[k], dist3 = vDists[k + 1];
+        const float deltaR = (dist1 - dist3) / (2.0f * (dist1 + dist3 - 2.0f * dist2));
+        if (!(deltaR < -1 || deltaR > 1)) {
+          float bestuR    = g.lv[levelL].scale * ((float)scaleduR0 + (float)bestinc + deltaR);
+          float disparity = (uL - bestuR);
+          if (disparity >= minD && disparity < maxD) {
+            if (disparity <= 0) {
+              disparity = 0.01;
+              bestuR    = uL - 0.01;
+            }
+            dOut   = a.mbf / disparity;
+            uOut   = bestuR;
+            sadOut = bestS;
+          }
+        }
+      }
+    }
+  }
+  if (lane == 0) {
+    a.uRight[iL] = uOut;
+    a.depth[iL]  = dOut;
+    a.sad[iL]    = sadOut;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_stereo_cut(StereoArgs a, int* kept) {
+  __shared__ int sMedian, sCount;
+  const int      tid = threadIdx.x;
+  if (tid == 0) sMedian = -1, sCount = 0;
+  __syncthreads();
+  int cnt = 0;
+  for (int i = tid; i < a.nl; i += 256) cnt += a.sad[i] >= 0;
+  atomicAdd(&sCount, cnt);
+  __syncthreads();
+  const int n = sCount;
+  if (n == 0) {
+    if (tid == 0) *kept = 0;
+    return;
+  }
+  // std::sort of (dist, iL) pairs, element n/2: its rank = #(smaller dist) + #(equal dist, smaller iL)
+  const int k = n / 2;
+  for (int i = tid; i < a.nl; i += 256) {
+    const int di = a.sad[i];
+    if (di < 0) continue;
+    int rank = 0;
+    for (int j = 0; j < a.nl; j++) {
+      const int dj = a.sad[j];
+      rank += (dj >= 0 && (dj < di || (dj == di && j < i))) ? 1 : 0;
+    }
+    if (rank == k) sMedian = di;
+  }
+  __syncthreads();
+  const float median = (float)sMedian;
+  const float thDist = 1.5f * 1.4f * median;
+  if (tid == 0) sCount = 0;
+  __syncthreads();
+  int keep = 0;
+  for (int i = tid; i < a.nl; i += 256) {
+    const int di = a.sad[i];
+    if (di < 0) continue;
+    if ((float)di < thDist) {
+      keep++;
+    } else {
+      a.uRight[i] = -1.0f;
+      a.depth[i]  = -1.0f;
+    }
+  }
+  atomicAdd(&sCount, keep);
+  __syncthreads();
+  if (tid == 0) *kept = sCount;
+}
+
+// ------------------------------------------------------------------------------------------------
 // PMC calibration: stream `n` bytes with W bytes per lane per load (W = 1, 4, 16) and fold them into one word,
 // so that rocprofv3's FETCH_SIZE can be compared with a known byte count for each access width this library
 // uses (MI355X_MICROARCH.md, HBM: the counter is only calibrated for 16 B/lane streams).

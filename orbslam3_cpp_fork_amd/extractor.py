@@ -141,6 +141,21 @@ class ORBextractor:
         return dict(zip(_lib.STAGE_NAMES, ms.tolist()))
 
 
+def ComputeStereoMatches(ex_left, ex_right, keys_left, desc_left, keys_right, desc_right, mb, mbf):
+    """Frame::ComputeStereoMatches (reference src/Frame.cc:944-1113) on the pyramids the two extractors hold on the device
+    after their last single-image call.  Returns (n_kept, mvuRight, mvDepth)."""
+    kl = np.ascontiguousarray(keys_left, KP_DTYPE)
+    kr = np.ascontiguousarray(keys_right, KP_DTYPE)
+    dl = np.ascontiguousarray(desc_left, np.uint8)
+    dr = np.ascontiguousarray(desc_right, np.uint8)
+    u, d = np.zeros(len(kl), np.float32), np.zeros(len(kl), np.float32)
+    n = check(
+        _lib.lib().orbx_stereo_matches(ex_left._h, ex_right._h, ptr(kl), ptr(dl), len(kl), ptr(kr), ptr(dr), len(kr), float(mb), float(mbf), ptr(u), ptr(d)),
+        "orbx_stereo_matches",
+    )
+    return n, u, d
+
+
 def octree_host_model(xs, ys, resp, W, H, N):
     """Host build of the kernel's quadtree core (octree_core.h) -- CPU tests only."""
     cand = (np.asarray(xs, np.uint32) | (np.asarray(ys, np.uint32) << 12) | (np.asarray(resp, np.uint32) << 24)).astype(np.uint32)

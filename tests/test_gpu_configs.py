@@ -108,3 +108,23 @@ def test_config5_rig_of_8_cameras(oracle):
         assert _same(ref, (int(cnt[f, 1]), k, d_desc[f, :n].cpu().numpy()))
         # W = 1920 > 1000: keypoints right of x = 1000 fill the front in natural order
         assert ref[0] > 0 and (k["x"][: ref[0]] > 1000).all() and (k["x"][ref[0]:] <= 1000).all()
+
+
+def test_stereo_matches_on_device_pyramids(oracle):
+    """SURVEY.md 8(f) N1: Frame::ComputeStereoMatches (src/Frame.cc:944-1113) on the two device-resident pyramids."""
+    from orbslam3_cpp_fork_amd import synth
+    from orbslam3_cpp_fork_amd.extractor import ComputeStereoMatches, ORBextractor
+
+    for cam, (h, w), nf in ((5, (376, 1241), 2000), (9, (480, 752), 1200)):
+        left, right = synth.make_stereo_pair(h, w, camera_idx=cam)
+        gl, gr = ORBextractor(nf), ORBextractor(nf)
+        _, kl, dl = gl(left, None, (0, 0))
+        _, kr, dr = gr(right, None, (0, 0))
+        ol, orr = oracle.OracleExtractor(nf), oracle.OracleExtractor(nf)
+        ol(left, (0, 0))
+        orr(right, (0, 0))
+        mb, mbf = 0.5372, 386.1448  # KITTI 00-02: bf = 386.1448, b = bf / fx
+        n0, u0, d0 = oracle.stereo_matches(ol, orr, kl, dl, kr, dr, mb, mbf)
+        n1, u1, d1 = ComputeStereoMatches(gl, gr, kl, dl, kr, dr, mb, mbf)
+        assert n0 == n1 and n0 > 50
+        assert (u0.view(np.uint32) == u1.view(np.uint32)).all() and (d0.view(np.uint32) == d1.view(np.uint32)).all()
