@@ -460,6 +460,41 @@ struct DevCtx {
 };
 #endif
 
+#if defined(__HIPCC__)
+// One wave = one problem: the scan and the reductions are pure cross-lane shuffles (no LDS, no barrier), and sync() only
+// has to make this wave's own global-memory writes visible to its other lanes before the next pass reads them.
+struct WaveCtx {
+  int  tid;  // lane
+  int  nt;   // 64
+  int* lds;  // 192 ints of sort work list
+  __device__ void sync() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
+  __device__ Int4 scan4(const Int4& v, Int4* total) {
+    Int4 inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int t = __shfl_up(inc.v[k], off, 64);
+        if (tid >= off) inc.v[k] += t;
+      }
+    }
+    Int4 ex;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      total->v[k] = __builtin_amdgcn_readlane(inc.v[k], 63);
+      ex.v[k]     = inc.v[k] - v.v[k];
+    }
+    return ex;
+  }
+  __device__ int min_reduce(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off, 64));
+    return v;
+  }
+  __device__ void sort(unsigned long long* buf, int n) { ot_wave_sort(buf, n, lds); }
+};
+#endif
+
 // chunk of [0, n) owned by this thread (contiguous, so that per-thread running counts are prefix counts)
 template <class CTX>
 OT_HD inline void ot_chunk(const CTX& c, int n, int* lo, int* hi) {

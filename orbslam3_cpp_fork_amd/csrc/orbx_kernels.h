@@ -497,7 +497,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(Bufs b, FrameGeom g, int ini
 // the feed order of the reference (cells row-major, row-major inside a cell), then runs octree_core.h.
 // ------------------------------------------------------------------------------------------------
 constexpr int kOctThreads  = 64;   // one wave per (frame, level): barriers degenerate to wave syncs and 16 problems are resident per CU
-constexpr int kOctLdsSort  = 2048;
+constexpr int kOctLdsSort  = 2048;  // sort records served from LDS
 
 __device__ __forceinline__ void octree_args(const Bufs& b, const FrameGeom& g, int f, int level, OtArgs* a) {
   const LevelGeom& L  = g.lv[level];
@@ -521,12 +521,13 @@ __device__ __forceinline__ void octree_args(const Bufs& b, const FrameGeom& g, i
 }
 
 __global__ __launch_bounds__(kOctThreads) void k_octree(Bufs b, FrameGeom g) {
-  __shared__ int                scratch[80 + 192];
+  static_assert(kOctThreads == 64, "k_octree runs one wave per (frame, level)");
+  __shared__ int                scratch[192];
   __shared__ unsigned long long ldsSort[kOctLdsSort];
   const int                     level = blockIdx.x, f = blockIdx.y;
   const LevelGeom&              L = g.lv[level];
-  DevCtx                        c;
-  c.tid = threadIdx.x, c.nt = kOctThreads, c.lds = scratch;
+  WaveCtx                       c;
+  c.tid = threadIdx.x, c.nt = 64, c.lds = scratch;
   OtArgs a;
   octree_args(b, g, f, level, &a);
   if (L.nodeCap <= kOctLdsSort) a.sortbuf = ldsSort;
@@ -545,7 +546,7 @@ __global__ __launch_bounds__(kOctThreads) void k_octree(Bufs b, FrameGeom g) {
     offs[i] = run;
     run += counts[i];
   }
-  __syncthreads();
+  c.sync();
   const int        n     = tot.v[0];
   const uint32_t*  slots = b.slots + (long long)f * g.totalSlots + L.slotBase;
   const int*       cslot = b.cellSlot + L.cellBase;
@@ -555,16 +556,16 @@ __global__ __launch_bounds__(kOctThreads) void k_octree(Bufs b, FrameGeom g) {
     for (int k = 0; k < cnt; k++) cand[o + k] = slots[sb + k];
   }
   if (c.tid == 0) b.candCount[(long long)f * g.nlevels + level] = n;
-  __syncthreads();
+  c.sync();
   a.n = n;
   ot_distribute(c, a);
 }
 
 // stand-alone quadtree on caller-supplied candidates (parity hook)
 __global__ __launch_bounds__(kOctThreads) void k_octree_only(OtArgs a) {
-  __shared__ int scratch[80 + 192];
-  DevCtx         c;
-  c.tid = threadIdx.x, c.nt = kOctThreads, c.lds = scratch;
+  __shared__ int scratch[192];
+  WaveCtx        c;
+  c.tid = threadIdx.x, c.nt = 64, c.lds = scratch;
   ot_distribute(c, a);
 }
 
