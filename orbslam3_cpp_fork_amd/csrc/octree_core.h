@@ -9,9 +9,12 @@
 //   * the list is an array stored in list order (index 0 = front); one step rebuilds it as
 //        [children of the nodes processed in this step, in reverse push order] ++ [surviving nodes, in order]
 //     which is what erase + push_front produce;
-//   * a node is a rectangle plus a contiguous range [start, start+cnt) of an index array over the
-//     candidates; DivideNode's stable 4-way split of vKeys (:513-526) becomes a stable 4-way partition
-//     of that range, computed for all nodes of a step at once with one prefix scan over the points;
+//   * a node is a rectangle plus a point COUNT; every candidate carries the index of the node that owns it.
+//     DivideNode's 4-way split of vKeys (:513-526) becomes: count the points of each child (one atomic add per
+//     point), create the children, relabel the points.  The points themselves never move: the only things the
+//     reference's per-node vectors are used for are their sizes and, at the very end, "the point with the largest
+//     response, the first one in the vector on ties" -- and the vector order inside a node is always the feed order,
+//     so that pick is max(response), then min(feed index), an order-free reduction;
 //   * std::sort (:685) is re-enacted operation for operation (libstdc++ bits/stl_algo.h: introsort with
 //     median-of-3 pivot, threshold 16, final insertion sort; heap-sort fallback included).
 //
@@ -36,13 +39,23 @@
 
 namespace orbx {
 
+// Node-level state is kept compact (64 bytes per node over all arrays) so that a whole problem fits in the LDS share of
+// one wave (see k_octree): coordinates and list indices are 16-bit (levels are < 4096 px, lists < 16384 nodes).
+typedef uint16_t OtIdx;
+constexpr int   kOtMaxNodes = 16383;   // node index + 2 quadrant bits in a 16-bit point label
+constexpr OtIdx kOtNone     = 0xffff;  // "not in D" (dIndex) / "no such child" (childIdx)
+
 struct OtNode {
-  int x0, x1, y0, y1;  // UL.x, UR.x, UL.y, BR.y (all four corners follow: the nodes are rectangles)
-  int start, cnt;      // range in the point index array
+  uint16_t x0, x1, y0, y1;  // UL.x, UR.x, UL.y, BR.y (all four corners follow: the nodes are rectangles)
+  int      cnt;             // vKeys.size()
 };
 
 struct Int4 {
   int v[4];
+};
+
+struct Idx4 {
+  OtIdx v[4];
 };
 
 // Candidate record: x | y << 12 | response << 24, coordinates relative to (minBorderX, minBorderY)
@@ -60,13 +73,15 @@ struct OtArgs {
   int             nIni;  // round(W / H), >= 1 (checked by the host)
   float           hX;    // (float)W / nIni
   int             maxNodes;
-  // workspace (global memory), sizes: points -> n, nodes -> maxNodes
-  int *               ordA, *ordB, *nodeOfA, *nodeOfB, *P;
-  uint8_t*            qv;
+  // workspace, sizes: points -> n, nodes -> maxNodes (<= kOtMaxNodes).  Every array may live in LDS or in global memory.
+  uint16_t*           nodeOf;  // per candidate: owner node (index into the current list) | child quadrant << 14
   OtNode *            nodesA, *nodesB;
-  Int4 *              startCnt, *endCnt;  // per node
-  int *               D, *dIndex, *nCh, *pushOff, *multiOff, *keptRank, *vA, *vB;
-  unsigned long long* sortbuf;  // >= maxNodes entries
+  Int4*               childCnt;  // per entry of D: points per child.           `best` may alias it (used after the last step)
+  Idx4*               childIdx;  // per entry of D: list index of each child.   `sortbuf` may alias it (consumed before step C)
+  unsigned long long* best;      // per node: (response << 32 | ~feed index) of its best point
+  OtIdx *             D, *dIndex, *pushOff, *multiOff, *keptRank, *vA, *vB;
+  uint8_t*            nCh;       // per entry of D: children | multi-point children << 4
+  unsigned long long* sortbuf;   // >= maxNodes entries
   // outputs
   uint32_t* outKp;  // kept candidates (same packing), list order
   int*      outCount;
@@ -239,6 +254,10 @@ struct HostCtx {
   }
   int  min_reduce(int v) { return v; }
   void sort(unsigned long long* buf, int n) { ot_std_sort(buf, n); }
+  void atomic_add(int* p, int v) { *p += v; }
+  void atomic_max(unsigned long long* p, unsigned long long v) { if (v > *p) *p = v; }
+  int  atomic_load(const int* p) const { return *p; }
+  unsigned long long atomic_load(const unsigned long long* p) const { return *p; }
 };
 
 #if defined(__HIPCC__)
@@ -492,6 +511,12 @@ struct WaveCtx {
     return v;
   }
   __device__ void sort(unsigned long long* buf, int n) { ot_wave_sort(buf, n, lds); }
+  // counters live in LDS or in global memory (generic pointers); reads go through the same agent-scope path as the
+  // atomics so that a line cached by an earlier plain load is never returned
+  __device__ void atomic_add(int* p, int v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  __device__ void atomic_max(unsigned long long* p, unsigned long long v) { __hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  __device__ int  atomic_load(const int* p) const { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  __device__ unsigned long long atomic_load(const unsigned long long* p) const { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 };
 #endif
 
@@ -509,8 +534,8 @@ OT_HD inline void ot_chunk(const CTX& c, int n, int* lo, int* hi) {
 
 // Exclusive scan of an int array of length n in place is not needed; what the algorithm needs is
 // "rank of flagged elements": out[i] = number of flagged j < i, plus the total.
-template <class CTX, class F>
-OT_HD inline int ot_rank_flags(CTX& c, int n, F flag, int* out) {
+template <class CTX, class F, class OUT>
+OT_HD inline int ot_rank_flags(CTX& c, int n, F flag, OUT* out) {
   int lo, hi;
   ot_chunk(c, n, &lo, &hi);
   Int4 loc = {{0, 0, 0, 0}};
@@ -519,7 +544,7 @@ OT_HD inline int ot_rank_flags(CTX& c, int n, F flag, int* out) {
   Int4 ex  = c.scan4(loc, &tot);
   int  run = ex.v[0];
   for (int i = lo; i < hi; i++) {
-    out[i] = run;
+    out[i] = (OUT)run;
     run += flag(i) ? 1 : 0;
   }
   c.sync();
@@ -533,72 +558,55 @@ OT_HD inline int ot_rank_flags(CTX& c, int n, F flag, int* out) {
 struct OtState {
   OtNode* nodes;
   OtNode* nodesNew;
-  int *   ord, *ordNew, *nodeOf, *nodeOfNew;
-  int *   v, *vNew;
+  OtIdx * v, *vNew;
   int     nNodes;
   int     nV;  // multi-point children created by the last step (vSizeAndPointerToNode)
 };
+
+// child quadrant of DivideNode (:480-526): n1,n2,n3,n4 = 0,1,2,3; the split lines are UL + ceil(half extent)
+OT_HD inline int ot_mid(int lo, int hi) { return lo + ((hi - lo + 1) >> 1); }
 
 template <class CTX>
 OT_HD inline void ot_divide_step(CTX& c, const OtArgs& a, OtState& s, int nD, bool mode_ordered) {
   if (a.dbgT && c.tid == 0) a.dbgT[2] += 1;
   const int n = a.n;
-  // -- A: classify every point of a flagged node into its child quadrant, prefix-count per quadrant
-  int lo, hi;
-  ot_chunk(c, n, &lo, &hi);
-  Int4 loc = {{0, 0, 0, 0}};
-  for (int i = lo; i < hi; i++) {
-    const int nd = s.nodeOf[i];
-    int       q  = 4;
-    if (a.dIndex[nd] >= 0) {
+  // -- A: count the points of every child of every flagged node (counters indexed by position in D)
+  for (int j = c.tid; j < nD; j += c.nt) a.childCnt[j] = Int4{{0, 0, 0, 0}};
+  c.sync();
+  for (int i = c.tid; i < n; i += c.nt) {
+    const int nd = a.nodeOf[i] & 0x3fff;
+    const int di = a.dIndex[nd];
+    if (di != kOtNone) {
       const OtNode   nn = s.nodes[nd];
-      const uint32_t cd = a.cand[s.ord[i]];
-      const int      mx = nn.x0 + ((nn.x1 - nn.x0 + 1) >> 1);  // UL.x + ceil((UR.x-UL.x)/2)
-      const int      my = nn.y0 + ((nn.y1 - nn.y0 + 1) >> 1);
-      q                 = (ot_cx(cd) < mx ? 0 : 1) + (ot_cy(cd) < my ? 0 : 2);  // n1,n2,n3,n4 = 0,1,2,3
-      loc.v[q]++;
-    }
-    a.qv[i] = (uint8_t)q;
-  }
-  Int4 tot;
-  Int4 run = c.scan4(loc, &tot);
-  for (int i = lo; i < hi; i++) {
-    const int nd = s.nodeOf[i];
-    if (i == 0 || s.nodeOf[i - 1] != nd) {
-      a.startCnt[nd] = run;
-      if (i > 0) a.endCnt[s.nodeOf[i - 1]] = run;
-    }
-    const int q = a.qv[i];
-    if (q < 4) {
-      a.P[i] = run.v[q];
-      run.v[q]++;
+      const uint32_t cd = a.cand[i];
+      const int      q  = (ot_cx(cd) < ot_mid(nn.x0, nn.x1) ? 0 : 1) + (ot_cy(cd) < ot_mid(nn.y0, nn.y1) ? 0 : 2);
+      a.nodeOf[i]       = (uint16_t)(nd | (q << 14));
+      c.atomic_add(&a.childCnt[di].v[q], 1);
     }
   }
-  if (hi == n && lo < hi) a.endCnt[s.nodeOf[n - 1]] = run;
   c.sync();
   // -- B: per processed node: children / multi-point children; exclusive offsets in processing order
   int dlo, dhi;
   ot_chunk(c, nD, &dlo, &dhi);
   Int4 l2 = {{0, 0, 0, 0}};
   for (int j = dlo; j < dhi; j++) {
-    const int d  = a.D[j];
-    int       ch = 0, mu = 0;
+    int ch = 0, mu = 0;
     for (int q = 0; q < 4; q++) {
-      int cq = a.endCnt[d].v[q] - a.startCnt[d].v[q];
+      const int cq = c.atomic_load(&a.childCnt[j].v[q]);
       ch += cq > 0;
       mu += cq > 1;
     }
-    a.nCh[j] = ch | (mu << 8);
+    a.nCh[j] = (uint8_t)(ch | (mu << 4));
     l2.v[0] += ch;
     l2.v[1] += mu;
   }
   Int4 t2;
   Int4 r2 = c.scan4(l2, &t2);
   for (int j = dlo; j < dhi; j++) {
-    a.pushOff[j]  = r2.v[0];
-    a.multiOff[j] = r2.v[1];
-    r2.v[0] += a.nCh[j] & 0xff;
-    r2.v[1] += a.nCh[j] >> 8;
+    a.pushOff[j]  = (OtIdx)r2.v[0];
+    a.multiOff[j] = (OtIdx)r2.v[1];
+    r2.v[0] += a.nCh[j] & 0xf;
+    r2.v[1] += a.nCh[j] >> 4;
   }
   c.sync();
   // -- break rule of the ordered phase: stop after the first processed node that brings the list to >= N
@@ -607,7 +615,7 @@ OT_HD inline void ot_divide_step(CTX& c, const OtArgs& a, OtState& s, int nD, bo
     int best = nD;
     for (int j = dlo; j < dhi; j++) {
       // list size after processing entries 0..j: + children - 1 each
-      int sizeAfter = s.nNodes + (a.pushOff[j] + (a.nCh[j] & 0xff)) - (j + 1);
+      int sizeAfter = s.nNodes + (a.pushOff[j] + (a.nCh[j] & 0xf)) - (j + 1);
       if (sizeAfter >= a.N) {
         best = j + 1;
         break;
@@ -618,61 +626,47 @@ OT_HD inline void ot_divide_step(CTX& c, const OtArgs& a, OtState& s, int nD, bo
   const int Ptot = (K < nD) ? a.pushOff[K] : t2.v[0];
   const int Mtot = (K < nD) ? a.multiOff[K] : t2.v[1];
   // -- rank of the surviving nodes
-  const int* dIndex = a.dIndex;
-  ot_rank_flags(c, s.nNodes, [dIndex, K](int i) { return !(dIndex[i] >= 0 && dIndex[i] < K); }, a.keptRank);
-  // -- C: write the new node array
+  const OtIdx* dIndex = a.dIndex;  // kOtNone compares above every K
+  ot_rank_flags(c, s.nNodes, [dIndex, K](int i) { return !(dIndex[i] < K); }, a.keptRank);
+  // -- C: write the new node array (children in reverse push order, then the survivors)
   for (int j = c.tid; j < K; j += c.nt) {
     const int    d  = a.D[j];
     const OtNode nn = s.nodes[d];
-    const int    mx = nn.x0 + ((nn.x1 - nn.x0 + 1) >> 1);
-    const int    my = nn.y0 + ((nn.y1 - nn.y0 + 1) >> 1);
-    const Int4   sc = a.startCnt[d], ec = a.endCnt[d];
-    int          k = 0, m = 0, st = nn.start;
-    Int4         childBase, childIdx;
+    const int    mx = ot_mid(nn.x0, nn.x1), my = ot_mid(nn.y0, nn.y1);
+    int          k = 0, m = 0;
+    Idx4         childIdx;
     for (int q = 0; q < 4; q++) {
-      const int cq   = ec.v[q] - sc.v[q];
-      childBase.v[q] = st - sc.v[q];
-      childIdx.v[q]  = -1;
+      const int cq  = c.atomic_load(&a.childCnt[j].v[q]);
+      childIdx.v[q] = kOtNone;
       if (cq > 0) {
         const int idx = Ptot - 1 - (a.pushOff[j] + k);
         OtNode    ch;
-        ch.x0 = (q & 1) ? mx : nn.x0;
-        ch.x1 = (q & 1) ? nn.x1 : mx;
-        ch.y0 = (q & 2) ? my : nn.y0;
-        ch.y1 = (q & 2) ? nn.y1 : my;
-        ch.start        = st;
+        ch.x0 = (uint16_t)((q & 1) ? mx : nn.x0);
+        ch.x1 = (uint16_t)((q & 1) ? nn.x1 : mx);
+        ch.y0 = (uint16_t)((q & 2) ? my : nn.y0);
+        ch.y1 = (uint16_t)((q & 2) ? nn.y1 : my);
         ch.cnt          = cq;
         s.nodesNew[idx] = ch;
-        childIdx.v[q]   = idx;
+        childIdx.v[q]   = (OtIdx)idx;
         if (cq > 1) {
-          s.vNew[a.multiOff[j] + m] = idx;
+          s.vNew[a.multiOff[j] + m] = (OtIdx)idx;
           m++;
         }
         k++;
       }
-      st += cq;
     }
-    a.startCnt[d] = childBase;  // reused by the point pass below
-    a.endCnt[d]   = childIdx;
+    a.childIdx[j] = childIdx;
   }
   for (int i = c.tid; i < s.nNodes; i += c.nt) {
     const int di = a.dIndex[i];
-    if (!(di >= 0 && di < K)) s.nodesNew[Ptot + a.keptRank[i]] = s.nodes[i];
+    if (!(di < K)) s.nodesNew[Ptot + a.keptRank[i]] = s.nodes[i];
   }
   c.sync();
-  // -- C': move the points (stable within every child), relabel their node
+  // -- C': relabel the points
   for (int i = c.tid; i < n; i += c.nt) {
-    const int nd = s.nodeOf[i];
+    const int lb = a.nodeOf[i], nd = lb & 0x3fff;
     const int di = a.dIndex[nd];
-    if (di >= 0 && di < K) {
-      const int q     = a.qv[i];
-      const int np    = a.startCnt[nd].v[q] + a.P[i];
-      s.ordNew[np]    = s.ord[i];
-      s.nodeOfNew[np] = a.endCnt[nd].v[q];
-    } else {
-      s.ordNew[i]    = s.ord[i];
-      s.nodeOfNew[i] = Ptot + a.keptRank[nd];
-    }
+    a.nodeOf[i]  = (uint16_t)((di < K) ? a.childIdx[di].v[lb >> 14] : Ptot + a.keptRank[nd]);
   }
   c.sync();
   const int newSize = Ptot + (s.nNodes - K);
@@ -681,19 +675,13 @@ OT_HD inline void ot_divide_step(CTX& c, const OtArgs& a, OtState& s, int nD, bo
     OtNode* tn = s.nodes;
     s.nodes    = s.nodesNew;
     s.nodesNew = tn;
-    int* t     = s.ord;
-    s.ord      = s.ordNew;
-    s.ordNew   = t;
-    t          = s.nodeOf;
-    s.nodeOf   = s.nodeOfNew;
-    s.nodeOfNew = t;
-    t          = s.v;
+    OtIdx* t   = s.v;
     s.v        = s.vNew;
     s.vNew     = t;
   }
   s.nNodes = newSize;
   s.nV     = Mtot;
-  for (int i = c.tid; i < newSize; i += c.nt) a.dIndex[i] = -1;
+  for (int i = c.tid; i < newSize; i += c.nt) a.dIndex[i] = kOtNone;
   c.sync();
 }
 
@@ -711,41 +699,34 @@ OT_HD inline void ot_distribute(CTX& c, const OtArgs& a) {
   }
   OtState s;
   s.nodes = a.nodesA, s.nodesNew = a.nodesB;
-  s.ord = a.ordA, s.ordNew = a.ordB;
-  s.nodeOf = a.nodeOfA, s.nodeOfNew = a.nodeOfB;
   s.v = a.vA, s.vNew = a.vB;
-  // ---- roots (:566-600): vpIniNodes[kp.pt.x / hX], stable; empty roots erased
-  // counting pass per root keeps the feed order inside each root
+  // ---- roots (:566-600): vpIniNodes[kp.pt.x / hX]; empty roots erased.  nIni <= maxNodes / 4 (host-checked).
   {
-    int base = 0, nn = 0;
-    for (int r = 0; r < a.nIni; r++) {
-      const uint32_t* cand = a.cand;
-      const float     hX   = a.hX;
-      int cnt = ot_rank_flags(c, n, [cand, hX, r](int i) { return (int)((float)ot_cx(cand[i]) / hX) == r; }, a.P);
-      for (int i = c.tid; i < n; i += c.nt) {
-        if ((int)((float)ot_cx(a.cand[i]) / a.hX) == r) {
-          s.ord[base + a.P[i]]    = i;
-          s.nodeOf[base + a.P[i]] = nn;
-        }
-      }
-      if (cnt > 0) {
-        if (c.tid == 0) {
-          OtNode nd;
-          nd.x0 = (int)(a.hX * (float)r);
-          nd.x1 = (int)(a.hX * (float)(r + 1));
-          nd.y0 = 0;
-          nd.y1 = a.H;
-          nd.start = base;
-          nd.cnt   = cnt;
-          s.nodes[nn] = nd;
-        }
-        nn++;
-      }
-      base += cnt;
-      c.sync();
+    Int4* rootCnt = a.childCnt;  // one counter per root in .v[0]
+    for (int r = c.tid; r < a.nIni; r += c.nt) rootCnt[r] = Int4{{0, 0, 0, 0}};
+    c.sync();
+    for (int i = c.tid; i < n; i += c.nt) {
+      const int r = (int)((float)ot_cx(a.cand[i]) / a.hX);
+      a.nodeOf[i] = (uint16_t)r;
+      c.atomic_add(&rootCnt[r].v[0], 1);
     }
+    c.sync();
+    const int nn = ot_rank_flags(c, a.nIni, [&c, rootCnt](int r) { return c.atomic_load(&rootCnt[r].v[0]) > 0; }, a.keptRank);
+    for (int r = c.tid; r < a.nIni; r += c.nt) {
+      const int cnt = c.atomic_load(&rootCnt[r].v[0]);
+      if (cnt > 0) {
+        OtNode nd;
+        nd.x0 = (uint16_t)(int)(a.hX * (float)r);
+        nd.x1 = (uint16_t)(int)(a.hX * (float)(r + 1));
+        nd.y0 = 0;
+        nd.y1 = (uint16_t)a.H;
+        nd.cnt = cnt;
+        s.nodes[a.keptRank[r]] = nd;
+      }
+    }
+    for (int i = c.tid; i < n; i += c.nt) a.nodeOf[i] = a.keptRank[a.nodeOf[i]];
     s.nNodes = nn;
-    for (int i = c.tid; i < nn; i += c.nt) a.dIndex[i] = -1;
+    for (int i = c.tid; i < nn; i += c.nt) a.dIndex[i] = kOtNone;
     c.sync();
   }
   // ---- main loop (:608-733)
@@ -757,7 +738,7 @@ OT_HD inline void ot_distribute(CTX& c, const OtArgs& a) {
     int nD = ot_rank_flags(c, s.nNodes, [nodes](int i) { return nodes[i].cnt > 1; }, a.keptRank);
     for (int i = c.tid; i < s.nNodes; i += c.nt) {
       if (s.nodes[i].cnt > 1) {
-        a.D[a.keptRank[i]] = i;
+        a.D[a.keptRank[i]] = (OtIdx)i;
         a.dIndex[i]        = a.keptRank[i];
       }
     }
@@ -784,8 +765,8 @@ OT_HD inline void ot_distribute(CTX& c, const OtArgs& a) {
         // processed from the back of the sorted vector (:686)
         for (int k = c.tid; k < V; k += c.nt) {
           const int node = s.v[(int)(a.sortbuf[V - 1 - k] & 0xffffu)];
-          a.D[k]         = node;
-          a.dIndex[node] = k;
+          a.D[k]         = (OtIdx)node;
+          a.dIndex[node] = (OtIdx)k;
         }
         c.sync();
         ot_divide_step(c, a, s, V, true);
@@ -793,16 +774,13 @@ OT_HD inline void ot_distribute(CTX& c, const OtArgs& a) {
       }
     }
   }
-  // ---- best point per node, first wins on ties, list order (:735-750)
-  for (int i = c.tid; i < s.nNodes; i += c.nt) {
-    const OtNode   nd   = s.nodes[i];
-    uint32_t       best = a.cand[s.ord[nd.start]];
-    for (int k = 1; k < nd.cnt; k++) {
-      const uint32_t cd = a.cand[s.ord[nd.start + k]];
-      if (ot_cr(cd) > ot_cr(best)) best = cd;
-    }
-    a.outKp[i] = best;
-  }
+  // ---- best point per node (:735-750): largest response, the earliest in feed order on ties
+  for (int i = c.tid; i < s.nNodes; i += c.nt) a.best[i] = 0ull;
+  c.sync();
+  for (int i = c.tid; i < n; i += c.nt)
+    c.atomic_max(&a.best[a.nodeOf[i] & 0x3fff], ((unsigned long long)(unsigned)ot_cr(a.cand[i]) << 32) | (unsigned long long)(0xffffffffu - (unsigned)i));
+  c.sync();
+  for (int i = c.tid; i < s.nNodes; i += c.nt) a.outKp[i] = a.cand[0xffffffffu - (unsigned)(c.atomic_load(&a.best[i]) & 0xffffffffull)];
   if (c.tid == 0) *a.outCount = s.nNodes;
   if (a.dbgT && c.tid == 0) a.dbgT[1] += OT_CLOCK() - tStart;
   c.sync();

@@ -93,16 +93,17 @@ struct orbx_extractor {
   int             capB     = 0;
   int             lastB    = 0;
   orbx::Bufs      bufs{};
-  DevBuf<uint8_t> dPyr, dBlur, dQv, dStage, dDescOut;
+  DevBuf<uint8_t> dPyr, dBlur, dNCh, dStage, dDescOut;
   DevBuf<int2>    dXtab, dYtab;
   DevBuf<int4>    dCellDesc;
   DevBuf<long long> dDbgT;
-  DevBuf<int>     dCellOrder, dCellSlot, dCellCount, dOrdA, dOrdB, dNodeOfA, dNodeOfB, dP, dD, dDIndex, dNCh, dPushOff, dMultiOff, dKeptRank, dVA,
-      dVB, dCandCount, dLvlCount, dOutIdx, dCounts;
+  DevBuf<int>     dCellOrder, dCellSlot, dCellCount, dCellOffs, dCandCount, dLvlCount, dOutIdx, dCounts;
+  DevBuf<uint16_t> dNodeOf, dD, dDIndex, dPushOff, dMultiOff, dKeptRank, dVA, dVB;
+  int              octLdsNodeCap = 0, octLdsPtsCap = 0, octLdsBytes = 0;  // dynamic LDS plan of k_octree (makeGeometry)
   DevBuf<uint32_t>           dSlots, dCand, dLvlKp;
   DevBuf<orbx::OtNode>       dNodesA, dNodesB;
-  DevBuf<orbx::Int4>         dStartCnt, dEndCnt;
-  DevBuf<unsigned long long> dSortbuf;
+  DevBuf<orbx::Int4>         dChildCnt;
+  DevBuf<orbx::Idx4>         dChildIdx;
   DevBuf<orbx::PatternTab>   dPattern;
   DevBuf<orbx::KpRec>        dKpOut;
   int                        stagePitch = 0;
@@ -186,6 +187,10 @@ int orbx_extractor::makeGeometry(int rows, int cols) {
     }
     L.hX       = width / L.nIni;
     L.nodeCap  = alignUp(std::max(L.N + 3, 4 * L.nIni) + 16, 16);
+    if (L.nodeCap > kOtMaxNodes) {
+      g_err = "more than 16383 quadtree nodes on one level is not supported";
+      return -2;
+    }
     L.nodeBase = nodeBase;
     nodeBase += L.nodeCap;
     L.kpCap  = std::max(L.N + 3, 4 * L.nIni);
@@ -290,6 +295,21 @@ int orbx_extractor::makeGeometry(int rows, int cols) {
   HIP_TRY(hipMemcpy(dXtab.p, xt.data(), xt.size() * sizeof(int2), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(dYtab.p, yt.data(), yt.size() * sizeof(int2), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(dCellSlot.p, cellSlot.data(), cellSlot.size() * sizeof(int), hipMemcpyHostToDevice));
+  // k_octree LDS plan: all node-level state of a level in LDS (kOctNodeBytes per node) plus as many 16-bit point labels
+  // as fit.  Up to ~20 KB per wave keeps 8 waves (= 8 problems) resident per CU; larger quotas trade residency for
+  // LDS, and beyond 64 KB the state stays in global memory.
+  {
+    int maxCap = 0;
+    for (int l = 0; l < nlevels; l++) maxCap = std::max(maxCap, g.lv[l].nodeCap);
+    const int fixed = kOctSortWork * 4, nodeBytes = maxCap * kOctNodeBytes;
+    if (fixed + nodeBytes + 2 * 512 <= 20224) {
+      octLdsNodeCap = maxCap, octLdsBytes = 20224, octLdsPtsCap = (octLdsBytes - fixed - nodeBytes) / 2;
+    } else if (fixed + nodeBytes <= 65536) {
+      octLdsNodeCap = maxCap, octLdsBytes = fixed + nodeBytes, octLdsPtsCap = 0;
+    } else {
+      octLdsNodeCap = 0, octLdsBytes = fixed, octLdsPtsCap = 0;
+    }
+  }
   geom     = g;
   haveGeom = true;
   capB     = 0;  // workspace must be re-laid out
@@ -304,18 +324,18 @@ int orbx_extractor::ensureWorkspace(int rows, int cols, int B) {
   const size_t           nb = (size_t)B;
   const size_t           np = nb * g.totalSlots, nn = nb * g.totalNodes;
   if (dPyr.ensure(nb * g.pyrBytes + 256) || dBlur.ensure(nb * g.blurBytes + 256) || dSlots.ensure(np) || dCellCount.ensure(nb * g.totalCells) ||
-      dCand.ensure(np) || dOrdA.ensure(np) || dOrdB.ensure(np) || dNodeOfA.ensure(np) || dNodeOfB.ensure(np) || dP.ensure(np) ||
-      dQv.ensure(np) || dNodesA.ensure(nn) || dNodesB.ensure(nn) || dStartCnt.ensure(nn) || dEndCnt.ensure(nn) || dD.ensure(nn) ||
+      dCand.ensure(np) || dNodeOf.ensure(np) || dCellOffs.ensure(nb * g.totalCells) ||
+      dNodesA.ensure(nn) || dNodesB.ensure(nn) || dChildCnt.ensure(nn) || dChildIdx.ensure(nn) || dD.ensure(nn) ||
       dDIndex.ensure(nn) || dNCh.ensure(nn) || dPushOff.ensure(nn) || dMultiOff.ensure(nn) || dKeptRank.ensure(nn) || dVA.ensure(nn) ||
-      dVB.ensure(nn) || dSortbuf.ensure(nn) || dCandCount.ensure(nb * g.nlevels) || dLvlKp.ensure(nb * g.totalKp) ||
+      dVB.ensure(nn) || dCandCount.ensure(nb * g.nlevels) || dLvlKp.ensure(nb * g.totalKp) ||
       dLvlCount.ensure(nb * g.nlevels) || dOutIdx.ensure(nb * g.totalKp))
     return -3;
   orbx::Bufs& b = bufs;
   b.pyr = dPyr.p, b.blur = dBlur.p, b.xtab = dXtab.p, b.ytab = dYtab.p, b.cellSlot = dCellSlot.p, b.cellOrder = dCellOrder.p, b.cellDesc = dCellDesc.p, b.slots = dSlots.p;
-  b.cellCount = dCellCount.p, b.cand = dCand.p, b.ordA = dOrdA.p, b.ordB = dOrdB.p, b.nodeOfA = dNodeOfA.p, b.nodeOfB = dNodeOfB.p;
-  b.P = dP.p, b.qv = dQv.p, b.nodesA = dNodesA.p, b.nodesB = dNodesB.p, b.startCnt = dStartCnt.p, b.endCnt = dEndCnt.p, b.D = dD.p;
+  b.cellCount = dCellCount.p, b.cand = dCand.p, b.nodeOf = dNodeOf.p, b.cellOffs = dCellOffs.p;
+  b.nodesA = dNodesA.p, b.nodesB = dNodesB.p, b.childCnt = dChildCnt.p, b.childIdx = dChildIdx.p, b.D = dD.p;
   b.dIndex = dDIndex.p, b.nCh = dNCh.p, b.pushOff = dPushOff.p, b.multiOff = dMultiOff.p, b.keptRank = dKeptRank.p, b.vA = dVA.p;
-  b.vB = dVB.p, b.sortbuf = dSortbuf.p, b.candCount = dCandCount.p, b.lvlKp = dLvlKp.p, b.lvlCount = dLvlCount.p, b.outIdx = dOutIdx.p;
+  b.vB = dVB.p, b.candCount = dCandCount.p, b.lvlKp = dLvlKp.p, b.lvlCount = dLvlCount.p, b.outIdx = dOutIdx.p;
   capB = B;
   return 0;
 }
@@ -388,7 +408,8 @@ int orbx_extractor::run(const uint8_t* d_imgs, int B, int rows, int cols, size_t
 #undef ORBX_LAUNCH_FAST
   }
   if (prof) HIP_TRY(hipEventRecord(ev[2], s));
-  hipLaunchKernelGGL(k_octree, dim3(g.nlevels, B), dim3(kOctThreads), 0, s, b, g);
+  // level-major grid: the large levels start first and every level spreads over all XCDs
+  hipLaunchKernelGGL(k_octree, dim3(B, g.nlevels), dim3(kOctThreads), octLdsBytes, s, b, g, octLdsNodeCap, octLdsPtsCap);
   if (prof) HIP_TRY(hipEventRecord(ev[3], s));
   hipLaunchKernelGGL(k_layout, dim3(B), dim3(256), 0, s, b, g, lap0, lap1, d_counts, cap);
   if (prof) HIP_TRY(hipEventRecord(ev[4], s));
@@ -490,12 +511,12 @@ void orbx_destroy(orbx_t* h) {
   if (h->evValid)
     for (auto& slot : h->ev)
       for (auto& e : slot) hipEventDestroy(e);
-  h->dPyr.release(), h->dBlur.release(), h->dQv.release(), h->dStage.release(), h->dDescOut.release(), h->dXtab.release(), h->dYtab.release();
-  h->dCellDesc.release(), h->dCellOrder.release(), h->dCellSlot.release(), h->dCellCount.release(), h->dOrdA.release(), h->dOrdB.release(), h->dNodeOfA.release(), h->dNodeOfB.release();
-  h->dP.release(), h->dD.release(), h->dDIndex.release(), h->dNCh.release(), h->dPushOff.release(), h->dMultiOff.release();
+  h->dPyr.release(), h->dBlur.release(), h->dStage.release(), h->dDescOut.release(), h->dXtab.release(), h->dYtab.release();
+  h->dCellDesc.release(), h->dCellOrder.release(), h->dCellSlot.release(), h->dCellCount.release(), h->dNodeOf.release(), h->dCellOffs.release();
+  h->dD.release(), h->dDIndex.release(), h->dNCh.release(), h->dPushOff.release(), h->dMultiOff.release();
   h->dKeptRank.release(), h->dVA.release(), h->dVB.release(), h->dCandCount.release(), h->dLvlCount.release(), h->dOutIdx.release();
   h->dCounts.release(), h->dSlots.release(), h->dCand.release(), h->dLvlKp.release(), h->dNodesA.release(), h->dNodesB.release();
-  h->dStartCnt.release(), h->dEndCnt.release(), h->dSortbuf.release(), h->dPattern.release(), h->dKpOut.release();
+  h->dChildCnt.release(), h->dChildIdx.release(), h->dPattern.release(), h->dKpOut.release();
   delete h;
 }
 
@@ -638,13 +659,15 @@ int orbx_debug_octree_device(orbx_t* h, const uint32_t* cand, int n, int W, int 
   const int    maxNodes = alignUp(std::max(N + 3, 4 * nIni) + 16, 16);
   const size_t np = (size_t)n + 16, nn = (size_t)maxNodes;
   DevBuf<uint32_t>           dc, dout;
-  DevBuf<int>                ordA, ordB, nA, nB, P, D, dI, nCh, pO, mO, kR, vA, vB, cnt;
-  DevBuf<uint8_t>            qv;
+  DevBuf<uint16_t>           nA, D, dI, pO, mO, kR, vA, vB;
+  DevBuf<int>                cnt;
+  DevBuf<uint8_t>            nCh;
   DevBuf<OtNode>             nodesA, nodesB;
-  DevBuf<Int4>               sc, ec;
-  DevBuf<unsigned long long> sb;
-  if (dc.ensure(np) || dout.ensure(nn) || ordA.ensure(np) || ordB.ensure(np) || nA.ensure(np) || nB.ensure(np) || P.ensure(np) ||
-      qv.ensure(np) || nodesA.ensure(nn) || nodesB.ensure(nn) || sc.ensure(nn) || ec.ensure(nn) || D.ensure(nn) || dI.ensure(nn) ||
+  DevBuf<Int4>               sc;
+  DevBuf<Idx4>               ec;
+  DevBuf<unsigned long long> sb, bst;
+  if (dc.ensure(np) || dout.ensure(nn) || nA.ensure(np) || bst.ensure(nn) ||
+      nodesA.ensure(nn) || nodesB.ensure(nn) || sc.ensure(nn) || ec.ensure(nn) || D.ensure(nn) || dI.ensure(nn) ||
       nCh.ensure(nn) || pO.ensure(nn) || mO.ensure(nn) || kR.ensure(nn) || vA.ensure(nn) || vB.ensure(nn) || sb.ensure(nn) || cnt.ensure(1))
     return -3;
   if (n > 0) HIP_TRY(hipMemcpy(dc.p, cand, (size_t)n * 4, hipMemcpyHostToDevice));
@@ -652,8 +675,8 @@ int orbx_debug_octree_device(orbx_t* h, const uint32_t* cand, int n, int W, int 
   memset(&a, 0, sizeof(a));
   a.dbgT = nullptr;
   a.cand = dc.p, a.n = n, a.W = W, a.H = H, a.N = N, a.nIni = nIni, a.hX = (float)W / nIni, a.maxNodes = maxNodes;
-  a.ordA = ordA.p, a.ordB = ordB.p, a.nodeOfA = nA.p, a.nodeOfB = nB.p, a.P = P.p, a.qv = qv.p, a.nodesA = nodesA.p, a.nodesB = nodesB.p;
-  a.startCnt = sc.p, a.endCnt = ec.p, a.D = D.p, a.dIndex = dI.p, a.nCh = nCh.p, a.pushOff = pO.p, a.multiOff = mO.p, a.keptRank = kR.p;
+  a.nodeOf = nA.p, a.best = bst.p, a.nodesA = nodesA.p, a.nodesB = nodesB.p;
+  a.childCnt = sc.p, a.childIdx = ec.p, a.D = D.p, a.dIndex = dI.p, a.nCh = nCh.p, a.pushOff = pO.p, a.multiOff = mO.p, a.keptRank = kR.p;
   a.vA = vA.p, a.vB = vB.p, a.sortbuf = sb.p, a.outKp = dout.p, a.outCount = cnt.p;
   hipLaunchKernelGGL(k_octree_only, dim3(1), dim3(kOctThreads), 0, h->stream, a);
   HIP_TRY(hipGetLastError());
@@ -662,8 +685,8 @@ int orbx_debug_octree_device(orbx_t* h, const uint32_t* cand, int n, int W, int 
   HIP_TRY(hipMemcpy(&c, cnt.p, sizeof(int), hipMemcpyDeviceToHost));
   if (c > 0) HIP_TRY(hipMemcpy(out, dout.p, (size_t)c * 4, hipMemcpyDeviceToHost));
   if (out_count) *out_count = c;
-  dc.release(), dout.release(), ordA.release(), ordB.release(), nA.release(), nB.release(), P.release(), D.release(), dI.release();
-  nCh.release(), pO.release(), mO.release(), kR.release(), vA.release(), vB.release(), cnt.release(), qv.release(), nodesA.release();
+  dc.release(), dout.release(), nA.release(), bst.release(), D.release(), dI.release();
+  nCh.release(), pO.release(), mO.release(), kR.release(), vA.release(), vB.release(), cnt.release(), nodesA.release();
   nodesB.release(), sc.release(), ec.release(), sb.release();
   return 0;
 }

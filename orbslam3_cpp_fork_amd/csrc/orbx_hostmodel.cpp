@@ -20,15 +20,17 @@ int orbx_debug_octree_host(const uint32_t* cand, int n, int W, int H, int N, uin
   OtArgs a;
   memset(&a, 0, sizeof(a));
   const int maxNodes = (N + 3 > 4 * nIni ? N + 3 : 4 * nIni) + 8;
-  std::vector<int>                ordA(n + 1), ordB(n + 1), nA(n + 1), nB(n + 1), P(n + 1);
-  std::vector<uint8_t>            qv(n + 1);
+  if (maxNodes > kOtMaxNodes) return -2;
+  std::vector<uint16_t>           nA(n + 1);
   std::vector<OtNode>             nodesA(maxNodes), nodesB(maxNodes);
-  std::vector<Int4>               sc(maxNodes), ec(maxNodes);
-  std::vector<int>                D(maxNodes), dI(maxNodes), nCh(maxNodes), pO(maxNodes), mO(maxNodes), kR(maxNodes), vA(maxNodes), vB(maxNodes);
-  std::vector<unsigned long long> sb(maxNodes);
+  std::vector<Int4>               sc(maxNodes);
+  std::vector<Idx4>               ec(maxNodes);
+  std::vector<OtIdx>              D(maxNodes), dI(maxNodes), pO(maxNodes), mO(maxNodes), kR(maxNodes), vA(maxNodes), vB(maxNodes);
+  std::vector<uint8_t>            nCh(maxNodes);
+  std::vector<unsigned long long> sb(maxNodes), bst(maxNodes);
   a.cand = cand, a.n = n, a.W = W, a.H = H, a.N = N, a.nIni = nIni, a.hX = (float)W / nIni, a.maxNodes = maxNodes;
-  a.ordA = ordA.data(), a.ordB = ordB.data(), a.nodeOfA = nA.data(), a.nodeOfB = nB.data(), a.P = P.data(), a.qv = qv.data();
-  a.nodesA = nodesA.data(), a.nodesB = nodesB.data(), a.startCnt = sc.data(), a.endCnt = ec.data();
+  a.nodeOf = nA.data(), a.best = bst.data();
+  a.nodesA = nodesA.data(), a.nodesB = nodesB.data(), a.childCnt = sc.data(), a.childIdx = ec.data();
   a.D = D.data(), a.dIndex = dI.data(), a.nCh = nCh.data(), a.pushOff = pO.data(), a.multiOff = mO.data();
   a.keptRank = kR.data(), a.vA = vA.data(), a.vB = vB.data(), a.sortbuf = sb.data();
   a.outKp = out, a.outCount = out_count;

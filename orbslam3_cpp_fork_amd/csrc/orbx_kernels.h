@@ -42,12 +42,14 @@ struct Bufs {
   int*           cellCount;  // [B][totalCells]
   // quadtree workspace, per frame: point arrays [totalSlots], node arrays [totalNodes]
   uint32_t*           cand;
-  int *               ordA, *ordB, *nodeOfA, *nodeOfB, *P;
-  uint8_t*            qv;
+  // (used when a level's state does not fit the LDS share of its wave -- see k_octree)
+  uint16_t*           nodeOf;
+  int*                cellOffs;  // [B][totalCells] feed-order offset of every cell
   OtNode *            nodesA, *nodesB;
-  Int4 *              startCnt, *endCnt;
-  int *               D, *dIndex, *nCh, *pushOff, *multiOff, *keptRank, *vA, *vB;
-  unsigned long long* sortbuf;
+  Int4*               childCnt;
+  Idx4*               childIdx;
+  OtIdx *             D, *dIndex, *pushOff, *multiOff, *keptRank, *vA, *vB;
+  uint8_t*            nCh;
   int*                candCount;  // [B][L]
   uint32_t*           lvlKp;      // [B][totalKp]
   int*                lvlCount;   // [B][L]
@@ -496,8 +498,9 @@ __global__ __launch_bounds__(256) void k_fast_cells(Bufs b, FrameGeom g, int ini
 // DistributeOctTree: one workgroup per (frame, level).  First gathers the per-cell candidate slots into
 // the feed order of the reference (cells row-major, row-major inside a cell), then runs octree_core.h.
 // ------------------------------------------------------------------------------------------------
-constexpr int kOctThreads  = 64;   // one wave per (frame, level): barriers degenerate to wave syncs and 16 problems are resident per CU
-constexpr int kOctLdsSort  = 2048;  // sort records served from LDS
+constexpr int kOctThreads   = 64;  // one wave per (frame, level): barriers degenerate to wave syncs
+constexpr int kOctNodeBytes = 64;  // LDS bytes per node over all node-level arrays (see ot_carve_lds)
+constexpr int kOctSortWork  = 192; // ints of sort work list
 
 __device__ __forceinline__ void octree_args(const Bufs& b, const FrameGeom& g, int f, int level, OtArgs* a) {
   const LevelGeom& L  = g.lv[level];
@@ -510,31 +513,52 @@ __device__ __forceinline__ void octree_args(const Bufs& b, const FrameGeom& g, i
   a->nIni    = L.nIni;
   a->hX      = L.hX;
   a->maxNodes = L.nodeCap;
-  a->ordA = b.ordA + po, a->ordB = b.ordB + po, a->nodeOfA = b.nodeOfA + po, a->nodeOfB = b.nodeOfB + po, a->P = b.P + po;
-  a->qv     = b.qv + po;
-  a->nodesA = b.nodesA + no, a->nodesB = b.nodesB + no, a->startCnt = b.startCnt + no, a->endCnt = b.endCnt + no;
+  a->nodeOf = b.nodeOf + po;
+  a->nodesA = b.nodesA + no, a->nodesB = b.nodesB + no, a->childCnt = b.childCnt + no, a->childIdx = b.childIdx + no;
+  a->best    = reinterpret_cast<unsigned long long*>(a->childCnt);
+  a->sortbuf = reinterpret_cast<unsigned long long*>(a->childIdx);
   a->D = b.D + no, a->dIndex = b.dIndex + no, a->nCh = b.nCh + no, a->pushOff = b.pushOff + no, a->multiOff = b.multiOff + no;
-  a->keptRank = b.keptRank + no, a->vA = b.vA + no, a->vB = b.vB + no, a->sortbuf = b.sortbuf + no;
+  a->keptRank = b.keptRank + no, a->vA = b.vA + no, a->vB = b.vB + no;
   a->outKp    = b.lvlKp + (long long)f * g.totalKp + L.kpBase;
   a->outCount = b.lvlCount + (long long)f * g.nlevels + level;
   a->dbgT     = b.dbgT ? b.dbgT + ((long long)f * g.nlevels + level) * 4 : nullptr;
 }
 
-__global__ __launch_bounds__(kOctThreads) void k_octree(Bufs b, FrameGeom g) {
+// Carve the node-level arrays (and, if they fit, the point labels) out of `lds`.  Layout per node: 2 x OtNode (24),
+// childCnt/best (16), childIdx/sortbuf (8), seven 16-bit index arrays (14), nCh (1, padded to 2) = 64 bytes.
+__device__ __forceinline__ void ot_carve_lds(OtArgs* a, unsigned char* lds, int nodeCap, int ptsCap) {
+  unsigned char* p = lds;
+  a->childCnt = reinterpret_cast<Int4*>(p), a->best = reinterpret_cast<unsigned long long*>(p), p += 16 * nodeCap;
+  a->childIdx = reinterpret_cast<Idx4*>(p), a->sortbuf = reinterpret_cast<unsigned long long*>(p), p += 8 * nodeCap;
+  a->nodesA = reinterpret_cast<OtNode*>(p), p += 12 * nodeCap;
+  a->nodesB = reinterpret_cast<OtNode*>(p), p += 12 * nodeCap;
+  OtIdx* q = reinterpret_cast<OtIdx*>(p);
+  a->D = q, q += nodeCap;
+  a->dIndex = q, q += nodeCap;
+  a->keptRank = q, q += nodeCap;
+  a->pushOff = q, q += nodeCap;
+  a->multiOff = q, q += nodeCap;
+  a->vA = q, q += nodeCap;
+  a->vB = q, q += nodeCap;
+  a->nCh = reinterpret_cast<uint8_t*>(q), q += nodeCap;
+  if (a->n <= ptsCap) a->nodeOf = q;
+}
+
+// ldsNodeCap: nodes the dynamic LDS block was sized for (0 = everything stays in global memory); ldsPtsCap: point labels.
+__global__ __launch_bounds__(kOctThreads) void k_octree(Bufs b, FrameGeom g, int ldsNodeCap, int ldsPtsCap) {
   static_assert(kOctThreads == 64, "k_octree runs one wave per (frame, level)");
-  __shared__ int                scratch[192];
-  __shared__ unsigned long long ldsSort[kOctLdsSort];
-  const int                     level = blockIdx.x, f = blockIdx.y;
-  const LevelGeom&              L = g.lv[level];
-  WaveCtx                       c;
+  extern __shared__ __align__(16) unsigned char ldsDyn[];
+  int*             scratch = reinterpret_cast<int*>(ldsDyn);  // sort work list
+  const int        level = blockIdx.y, f = blockIdx.x;
+  const LevelGeom& L = g.lv[level];
+  WaveCtx          c;
   c.tid = threadIdx.x, c.nt = 64, c.lds = scratch;
   OtArgs a;
   octree_args(b, g, f, level, &a);
-  if (L.nodeCap <= kOctLdsSort) a.sortbuf = ldsSort;
   // feed order: exclusive scan of the cell counts, then copy the slots
   const int  nc     = L.nCols * L.nRows;
   const int* counts = b.cellCount + (long long)f * g.totalCells + L.cellBase;
-  int*       offs   = a.P;  // scratch (nc <= slotCount)
+  int*       offs   = b.cellOffs + (long long)f * g.totalCells + L.cellBase;
   int        lo, hi;
   ot_chunk(c, nc, &lo, &hi);
   Int4 loc = {{0, 0, 0, 0}};
@@ -547,23 +571,25 @@ __global__ __launch_bounds__(kOctThreads) void k_octree(Bufs b, FrameGeom g) {
     run += counts[i];
   }
   c.sync();
-  const int        n     = tot.v[0];
-  const uint32_t*  slots = b.slots + (long long)f * g.totalSlots + L.slotBase;
-  const int*       cslot = b.cellSlot + L.cellBase;
-  uint32_t*        cand  = b.cand + (long long)f * g.totalSlots + L.slotBase;
+  const int                    n     = tot.v[0];
+  const uint32_t* __restrict__ slots = b.slots + (long long)f * g.totalSlots + L.slotBase;
+  const int*                   cslot = b.cellSlot + L.cellBase;
+  uint32_t* __restrict__       cand  = b.cand + (long long)f * g.totalSlots + L.slotBase;
   for (int cidx = c.tid; cidx < nc; cidx += c.nt) {
     const int cnt = counts[cidx], o = offs[cidx], sb = cslot[cidx];
+#pragma unroll 4
     for (int k = 0; k < cnt; k++) cand[o + k] = slots[sb + k];
   }
   if (c.tid == 0) b.candCount[(long long)f * g.nlevels + level] = n;
   c.sync();
   a.n = n;
+  if (L.nodeCap <= ldsNodeCap) ot_carve_lds(&a, ldsDyn + kOctSortWork * 4, L.nodeCap, ldsPtsCap);
   ot_distribute(c, a);
 }
 
 // stand-alone quadtree on caller-supplied candidates (parity hook)
 __global__ __launch_bounds__(kOctThreads) void k_octree_only(OtArgs a) {
-  __shared__ int scratch[192];
+  __shared__ int scratch[kOctSortWork];
   WaveCtx        c;
   c.tid = threadIdx.x, c.nt = 64, c.lds = scratch;
   ot_distribute(c, a);
