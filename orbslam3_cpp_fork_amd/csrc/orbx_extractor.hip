@@ -385,25 +385,27 @@ int orbx_extractor::run(const uint8_t* d_imgs, int B, int rows, int cols, size_t
     // pyramid levels are 64-byte pitched and 256-byte based; level 0 is the caller's buffer
     const bool al4 = (step % 4 == 0) && (frameStride % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_imgs) & 3) == 0);
     const int dbg = getenv("ORBX_DBG_SKIP_FAST") ? atoi(getenv("ORBX_DBG_SKIP_FAST")) : 0;  // ablation switch (tuning)
-    // tile dwords per thread for this geometry: tiles are staged from the aligned column below iniX (up to +3)
-    int maxN4 = 0;
-    for (int l = 0; l < g.nlevels; l++) maxN4 = std::max(maxN4, ((3 + g.lv[l].wCell + 6 + 3) / 4) * (g.lv[l].hCell + 6));
-    const int npre = (maxN4 + 255) / 256;
-#define ORBX_LAUNCH_FAST(AL, NP) hipLaunchKernelGGL((k_fast_cells<AL, NP>), grid, dim3(256), 0, s, b, g, t1, t2, fastGrid, dbg)
+    // tile geometry of this image size: tiles are staged from the aligned column below iniX (up to +3 columns)
+    int maxW = 0, maxH = 0;
+    for (int l = 0; l < g.nlevels; l++) maxW = std::max(maxW, g.lv[l].wCell), maxH = std::max(maxH, g.lv[l].hCell);
+    const bool    small = maxW + 9 <= 52 && ((maxW + 9 + 3) / 4) * (maxH + 6) <= 3 * 256;
+    const int     tsSel = small ? 52 : kFastTileMax;
+    orbx::FastLds fl;
+    fl.tileBytes = alignUp(tsSel * (maxH + 6), 16);
+    fl.maxInt    = alignUp(maxW * maxH, 2);
+    fl.kpCap     = ((maxW + 1) / 2) * ((maxH + 1) / 2) + 64;
+    const size_t ldsBytes = 2 * (size_t)fl.tileBytes + 2 * (size_t)(fl.maxInt + fl.kpCap);
+#define ORBX_LAUNCH_FAST(AL, NP, TS) hipLaunchKernelGGL((k_fast_cells<AL, NP, TS>), grid, dim3(256), ldsBytes, s, b, g, t1, t2, fastGrid, dbg, fl)
     if (al4) {
-      if (npre <= 2)
-        ORBX_LAUNCH_FAST(true, 2);
-      else if (npre <= 3)
-        ORBX_LAUNCH_FAST(true, 3);
-      else if (npre <= 4)
-        ORBX_LAUNCH_FAST(true, 4);
+      if (small)
+        ORBX_LAUNCH_FAST(true, 3, 52);
       else
-        ORBX_LAUNCH_FAST(true, kFastPrefetchMax);
+        ORBX_LAUNCH_FAST(true, kFastPrefetchMax, kFastTileMax);
     } else {
-      if (npre <= 3)
-        ORBX_LAUNCH_FAST(false, 3);
+      if (small)
+        ORBX_LAUNCH_FAST(false, 3, 52);
       else
-        ORBX_LAUNCH_FAST(false, kFastPrefetchMax);
+        ORBX_LAUNCH_FAST(false, kFastPrefetchMax, kFastTileMax);
     }
 #undef ORBX_LAUNCH_FAST
   }

@@ -241,6 +241,31 @@ __device__ __forceinline__ void fast_score2(const uint8_t* __restrict__ cA, cons
   *sB           = sc.y;
 }
 
+// Corner score of ONE pixel with both polarities packed: low half d = v - p, high half -d.  min over an arc of the low
+// halves is the dark-arc margin, of the high halves the bright-arc margin, so one chain of packed mins serves both and
+// score = max(low, high of the max over the 16 arcs) - 1.  Half the live registers of the two-pixel form.
+__device__ __forceinline__ int fast_score_pm(const uint8_t* __restrict__ c, int ts) {
+  const int off[16] = {3 * ts,      3 * ts + 1,  2 * ts + 2,  ts + 3, 3, -ts + 3, -2 * ts + 2, -3 * ts + 1,
+                       -3 * ts,     -3 * ts - 1, -2 * ts - 2, -ts - 3, -3, ts - 3,  2 * ts - 2,  3 * ts - 1};
+  const int  v0 = c[0];
+  const pk16 vv = pk_pair(v0, 0x10000 - v0);  // (v, -v)
+  pk16       e[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    const int pk = c[off[k]];
+    e[k]         = vv - pk_pair(pk, 0x10000 - pk);  // (v - p, p - v)
+  }
+  pk16 m2[16], m4[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) m2[i] = pk_min(e[i], e[(i + 1) & 15]);
+#pragma unroll
+  for (int i = 0; i < 16; i++) m4[i] = pk_min(m2[i], m2[(i + 2) & 15]);
+  pk16 A = pk_pair(0xfc18, 0xfc18);  // -1000
+#pragma unroll
+  for (int i = 0; i < 16; i++) A = pk_max(A, pk_min(pk_min(m4[i], m4[(i + 4) & 15]), e[(i + 8) & 15]));
+  return max((int)A.x, (int)A.y) - 1;
+}
+
 // Workgroup barrier that waits for this wave's LDS traffic only.  __syncthreads() also drains vmcnt, which would
 // stall every wave on the next cell's prefetch loads at the first barrier after they were issued.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -321,16 +346,29 @@ __device__ __forceinline__ void fast_prefetch(const FastCell& c, int tid, uint32
 }
 
 // NPRE = tile dwords per thread for THIS image geometry (ceil(max tile dwords / 256); 3 at VGA, 7 worst case).
-template <bool AL4, int NPRE>
-__global__ __launch_bounds__(256) void k_fast_cells(Bufs b, FrameGeom g, int iniTh, int minTh, int nslots, int dbgSkip) {
-  constexpr int                     kMaxInt = (kFastTileMax - 6) * (kFastTileMax - 6);  // interior pixels of the largest tile
-  __shared__ __align__(16) uint8_t  tile[kFastTileMax][kFastTileMax];   // pixels
-  __shared__ __align__(16) uint8_t  score[kFastTileMax][kFastTileMax];  // corner score (0 = not a corner at lowTh)
-  __shared__ unsigned short         candList[kMaxInt];                  // pass-1 survivors (pixel index in the interior)
-  __shared__ unsigned short         kpList[kMaxInt / 2 + 64];           // NMS survivors under either threshold
-  __shared__ int                    candCount, kpCount, cnt1, cnt2;
-  constexpr int                     ts = kFastTileMax;  // row stride of the tile
-  const uint8_t*                    tl = &tile[0][0];
+// TS = LDS row stride of the tile (compile-time so that the 16 circle taps are immediate offsets): 52 covers every level
+// with at least four cell columns (cells <= 43 px wide), 80 the largest possible cell.  The LDS block is sized by the host
+// for the actual geometry (FastLds); at VGA it is ~10 KB, which together with the 64-register budget of the TS = 52
+// instantiation keeps 8 waves per SIMD resident -- the kernel spends half of its time behind barriers and LDS latency,
+// and residency is what hides that.
+struct FastLds {
+  int tileBytes;  // TS * (max tile height), multiple of 16
+  int maxInt;     // interior pixels of the largest cell (candList capacity), even
+  int kpCap;      // NMS survivors: at most one per 2x2 block, + 64
+};
+
+template <bool AL4, int NPRE, int TS>
+__global__ __launch_bounds__(256, TS <= 52 ? 8 : 5) void k_fast_cells(Bufs b, FrameGeom g, int iniTh, int minTh, int nslots, int dbgSkip, FastLds fl) {
+  extern __shared__ __align__(16) uint8_t fastLds[];
+  uint8_t*        tile     = fastLds;                  // pixels, row stride TS
+  uint8_t*        score    = fastLds + fl.tileBytes;   // corner score (0 = not a corner at lowTh)
+  unsigned short* candList = reinterpret_cast<unsigned short*>(fastLds + 2 * fl.tileBytes);  // pass-1 survivors (pixel index in the interior)
+  // NMS survivors under either threshold.  No two of them are 8-neighbours (a survivor at minTh beats every neighbour; one
+  // at iniTh beats every neighbour that reaches iniTh, and a neighbouring minTh survivor would), hence the capacity.
+  unsigned short* kpList = candList + fl.maxInt;
+  __shared__ int  candCount, kpCount, cnt1, cnt2;
+  constexpr int   ts = TS;
+  const uint8_t*  tl = tile;
   // Workgroup b walks kFastCellsPerBlock consecutive slots of XCD (b % 8)'s list in the host-built order table
   // (whole cell ROWS dealt to the 8 XCDs, balanced by cell count: horizontally adjacent cells share 128-B lines and
   // the 6-px overlap, so they sit behind one L2).  While a cell is processed the NEXT cell's tile is already in
@@ -355,14 +393,14 @@ __global__ __launch_bounds__(256) void k_fast_cells(Bufs b, FrameGeom g, int ini
     const int iw = cur.iw, ih = cur.ih;
     const unsigned   mIw = iw == 1 ? 0u : 0xffffffffu / (unsigned)iw + 1u;  // interior-width divider for idx -> (row, col)
     const int        ox3 = 3 + cur.ox;  // LDS column of interior column 0
-    // registers -> LDS (kFastTileMax is a multiple of 4: aligned; spill past tw stays inside the row)
+    // registers -> LDS (TS is a multiple of 4: aligned; spill past tw stays inside the row)
 #pragma unroll
     for (int k = 0; k < NPRE; k++) {
       const int idx = tid + k * 256;
       if (idx < cur.n4) {
         const int y = div_magic(idx, cur.mT4), x = (idx - y * cur.tw4) * 4;
-        *reinterpret_cast<uint32_t*>(&tile[y][x])  = pre[k];
-        *reinterpret_cast<uint32_t*>(&score[y][x]) = 0;
+        *reinterpret_cast<uint32_t*>(tile + y * ts + x)  = pre[k];
+        *reinterpret_cast<uint32_t*>(score + y * ts + x) = 0;
       }
     }
     if (tid == 0) candCount = 0, kpCount = 0, cnt1 = 0, cnt2 = 0;
@@ -421,15 +459,11 @@ __global__ __launch_bounds__(256) void k_fast_cells(Bufs b, FrameGeom g, int ini
     lds_barrier();
     // Pass 2 -- full corner score of the survivors
     const int ncand = candCount;
-    const int nhalf = (ncand + 1) >> 1;  // two candidates per lane: k and k + nhalf
-    for (int k = tid; k < ((dbgSkip & 2) ? 0 : nhalf); k += 256) {
-      const int idxA = candList[k], idxB = candList[min(k + nhalf, ncand - 1)];
-      const int qa = div_magic(idxA, mIw), ya = 3 + qa, xa = ox3 + idxA - qa * iw;
-      const int qb = div_magic(idxB, mIw), yb = 3 + qb, xb = ox3 + idxB - qb * iw;
-      int       sA, sB;
-      fast_score2(tl + ya * ts + xa, tl + yb * ts + xb, ts, &sA, &sB);
-      score[ya][xa] = (uint8_t)(sA >= lowTh ? sA : 0);  // scores below both thresholds are never corners
-      score[yb][xb] = (uint8_t)(sB >= lowTh ? sB : 0);  // (B duplicates A's last element when ncand is odd: same value)
+    for (int k = tid; k < ((dbgSkip & 2) ? 0 : ncand); k += 256) {
+      const int idx = candList[k];
+      const int q = div_magic(idx, mIw), y = 3 + q, x = ox3 + idx - q * iw;
+      const int sc = fast_score_pm(tl + y * ts + x, ts);
+      score[y * ts + x] = (uint8_t)(sc >= lowTh ? sc : 0);  // scores below both thresholds are never corners
     }
     lds_barrier();
     // Pass 3 -- strict 3x3 NMS under both thresholds, over the survivors only.  Flags go to a sparse list.
@@ -439,7 +473,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(Bufs b, FrameGeom g, int ini
       if (k < ncand) {
         idx = candList[k];
         const int q = div_magic(idx, mIw), y = 3 + q, x = ox3 + idx - q * iw;
-        const int s = score[y][x];
+        const int s = score[y * ts + x];
         if (s > 0) {
           int m1 = 0, m2 = 0;  // max neighbour score under each threshold
 #pragma unroll
@@ -447,7 +481,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(Bufs b, FrameGeom g, int ini
 #pragma unroll
             for (int dx = -1; dx <= 1; dx++)
               if (dx | dy) {
-                const int t = score[y + dy][x + dx];
+                const int t = score[(y + dy) * ts + x + dx];
                 m2          = max(m2, t);
                 m1          = max(m1, t >= iniTh ? t : 0);
               }
@@ -483,7 +517,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(Bufs b, FrameGeom g, int ini
           rank += ((ot & selB) && (int)(ot & 0x3fff) < idx) ? 1 : 0;
         }
         const int q = div_magic(idx, mIw), y = 3 + q, x = ox3 + idx - q * iw;
-        out[rank]   = (uint32_t)(x - cur.ox + xoff) | ((uint32_t)(y + yoff) << 12) | ((uint32_t)score[y][x] << 24);
+        out[rank]   = (uint32_t)(x - cur.ox + xoff) | ((uint32_t)(y + yoff) << 12) | ((uint32_t)score[y * ts + x] << 24);
       }
     }
     lds_barrier();  // tile / score / lists are rewritten by the next cell
