@@ -270,7 +270,7 @@ __device__ __forceinline__ int fast_score_pm(const uint8_t* __restrict__ c, int 
 // stall every wave on the next cell's prefetch loads at the first barrier after they were issued.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-constexpr int kFastCellsPerBlock = 4;  // cells walked by one (persistent) workgroup
+constexpr int kFastCellsPerBlock = 1;  // cells walked by one (persistent) workgroup
 constexpr int kFastPrefetchMax   = 7;  // tile dwords a thread may hold in flight: ceil(20 * 77 / 256) for the largest tile
 
 struct FastCell {

@@ -249,9 +249,23 @@ __global__ __launch_bounds__(256) void k_group_topk(GroupArgs a0) {
 // DBoW2 form, whose candidate lists are short and differ per query.
 constexpr int kBfTile = 256;  // train rows staged in LDS per step (8 KB)
 
+// popcount with accumulate, pinned: left to itself the compiler turns the 8-term sum into independent popcounts plus an
+// add tree (11 VALU per distance); the accumulate operand of v_bcnt makes it 8, and four rows in flight hide the chain.
+__device__ __forceinline__ int popc0(uint32_t x) {
+  int r;
+  asm("v_bcnt_u32_b32 %0, %1, 0" : "=v"(r) : "v"(x));
+  return r;
+}
+__device__ __forceinline__ int popc_acc(uint32_t x, int acc) {
+  int r;
+  asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
+  return r;
+}
+
+template <bool TVALID>
 __global__ __launch_bounds__(256) void k_bf_topk(GroupArgs a0) {
   __shared__ __align__(16) uint4 tile[2][kBfTile][2];  // double-buffered train descriptors
-  __shared__ uint8_t             tval[2][kBfTile];
+  __shared__ uint8_t             tval[2][TVALID ? kBfTile : 1];
   const GroupArgs a   = pair_view(a0, blockIdx.y);
   const int       tid = threadIdx.x;
   const int       nq  = a.d_nq ? *a.d_nq : a.nq;
@@ -275,7 +289,7 @@ __global__ __launch_bounds__(256) void k_bf_topk(GroupArgs a0) {
     if (row < nt) {
       tile[buf][tid][0] = *reinterpret_cast<const uint4*>(a.t + (size_t)row * 32);
       tile[buf][tid][1] = *reinterpret_cast<const uint4*>(a.t + (size_t)row * 32 + 16);
-      tval[buf][tid]    = a.t_valid ? a.t_valid[row] : 1;
+      if (TVALID) tval[buf][tid] = a.t_valid[row];
     }
   };
   stage(0, 0);
@@ -286,11 +300,13 @@ __global__ __launch_bounds__(256) void k_bf_topk(GroupArgs a0) {
     const int n = min(kBfTile, nt - base);
     auto dist = [&](int r) {
       const uint4 b0 = tile[buf][r][0], b1 = tile[buf][r][1];  // same LDS address in every lane: broadcast
-      return __popc(a0v.x ^ b0.x) + __popc(a0v.y ^ b0.y) + __popc(a0v.z ^ b0.z) + __popc(a0v.w ^ b0.w) + __popc(a1v.x ^ b1.x) +
-             __popc(a1v.y ^ b1.y) + __popc(a1v.z ^ b1.z) + __popc(a1v.w ^ b1.w);
+      int d = popc0(a0v.x ^ b0.x);
+      d     = popc_acc(a0v.y ^ b0.y, d), d = popc_acc(a0v.z ^ b0.z, d), d = popc_acc(a0v.w ^ b0.w, d);
+      d     = popc_acc(a1v.x ^ b1.x, d), d = popc_acc(a1v.y ^ b1.y, d), d = popc_acc(a1v.z ^ b1.z, d);
+      return popc_acc(a1v.w ^ b1.w, d);
     };
     auto consider = [&](int r, int d) {
-      if (d < dstar && active && tval[buf][r]) {
+      if (d < dstar && active && (!TVALID || tval[buf][r])) {
         cnt++;
         uint32_t key = ((uint32_t)d << kPosBits) | (uint32_t)(base + r);
 #pragma unroll
@@ -883,8 +899,10 @@ static int launch_groups(orbm_matcher* h, GroupArgs& a, int nq_cap, hipStream_t 
   if (nqe > 0) {
     if (a.q_idx)
       hipLaunchKernelGGL(k_group_topk, dim3((nqe + 3) / 4, npairs), dim3(256), 0, s, a);
+    else if (a.t_valid)
+      hipLaunchKernelGGL(k_bf_topk<true>, dim3((nqe + 255) / 256, npairs), dim3(256), 0, s, a);
     else
-      hipLaunchKernelGGL(k_bf_topk, dim3((nqe + 255) / 256, npairs), dim3(256), 0, s, a);
+      hipLaunchKernelGGL(k_bf_topk<false>, dim3((nqe + 255) / 256, npairs), dim3(256), 0, s, a);
   }
   hipLaunchKernelGGL(k_group_resolve, dim3(npairs), dim3(kResolveThreads), 0, s, a);
   HIP_TRYM(hipGetLastError());
