@@ -201,11 +201,12 @@ int orbx_extractor::makeGeometry(int rows, int cols) {
     // blur tiles
     L.blurTilesX   = (L.w + 3) / 4;                          // 4-column groups
     L.blurTilesY   = (L.h + kBlurRows - 1) / kBlurRows;      // row strips
-    L.blurTileBase = tileBase;                               // in workgroups of 256 items
     {
-      // worst case of the interior / edge split made by k_blur_levels (unaligned level 0: every group is "edge")
-      const int nInt = std::max((L.w - 8) >> 2, 0), nEdge = L.blurTilesX - nInt;
-      tileBase += std::max((nInt * L.blurTilesY + 255) / 256 + (nEdge * L.blurTilesY + 255) / 256, (L.blurTilesX * L.blurTilesY + 255) / 256);
+      // interior groups (12-byte window inside the row) go to k_blur_levels, the 2-3 edge groups of every strip to
+      // k_blur_edges; an unaligned level 0 sends ALL its groups to the edge kernel, so that grid is sized for it
+      const int nInt = std::max((L.w - 8) >> 2, 0);
+      L.blurTileBase = tileBase;  // in workgroups of 256 items
+      tileBase += (nInt * L.blurTilesY + 255) / 256;
     }
     // cv::resize INTER_LINEAR tables (OpenCV resize.cpp)
     L.xtabOff = (int)xt.size();
@@ -366,6 +367,21 @@ int orbx_extractor::run(const uint8_t* d_imgs, int B, int rows, int cols, size_t
     evValid = true;
   }
   hipEvent_t* ev = this->ev[profCount % kProfSlots];
+  // level 0 is the caller's buffer: aligned-dword paths need its base, pitch and frame stride 4-byte aligned
+  const bool al4 = (step % 4 == 0) && (frameStride % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_imgs) & 3) == 0);
+  const int  l0a = al4 ? 1 : 0;
+  // blur: interior groups -> k_blur_levels, edge columns -> k_blur_edges, an unaligned level 0 -> k_blur_level0_bytes
+  auto launchBlur = [&](hipStream_t st) {
+    const FrameGeom& gg = geom;
+    int              edgeBlocks = 0;
+    for (int l = al4 ? 0 : 1; l < gg.nlevels; l++) edgeBlocks += blur_edge_blocks(gg.lv[l]);
+    hipLaunchKernelGGL(k_blur_levels, dim3(8 * ((gg.totalBlurTiles + 7) / 8), B), dim3(256), 0, st, bufs, gg, l0a);
+    if (edgeBlocks > 0) hipLaunchKernelGGL(k_blur_edges, dim3(edgeBlocks, B), dim3(256), 0, st, bufs, gg, al4 ? 0 : 1);
+    if (!al4) {
+      const int items = ((gg.lv[0].w + 3) / 4) * ((gg.lv[0].h + kBlurEdgeRows - 1) / kBlurEdgeRows);
+      hipLaunchKernelGGL(k_blur_level0_bytes, dim3((items + 255) / 256, B), dim3(256), 0, st, bufs, gg);
+    }
+  };
   if (prof) HIP_TRY(hipEventRecord(ev[0], s));
   for (int l = 1; l < g.nlevels; l++) {
     dim3 grid((g.lv[l].w + kRsTileW - 1) / kRsTileW, (g.lv[l].h + kRsTileH - 1) / kRsTileH, B), block(256, 1, 1);
@@ -374,7 +390,7 @@ int orbx_extractor::run(const uint8_t* d_imgs, int B, int rows, int cols, size_t
   if (overlapBlur) {  // fork: the blur only needs the pyramid
     HIP_TRY(hipEventRecord(evFork, s));
     HIP_TRY(hipStreamWaitEvent(stream2, evFork, 0));
-    hipLaunchKernelGGL(k_blur_levels, dim3(8 * ((g.totalBlurTiles + 7) / 8), B), dim3(256), 0, stream2, b, g);
+    launchBlur(stream2);
     HIP_TRY(hipEventRecord(evJoin, stream2));
   }
   if (prof) HIP_TRY(hipEventRecord(ev[1], s));
@@ -382,8 +398,6 @@ int orbx_extractor::run(const uint8_t* d_imgs, int B, int rows, int cols, size_t
     const int  per  = fastGrid / 8;  // order-table slots per XCD
     const dim3 grid(8 * ((per + kFastCellsPerBlock - 1) / kFastCellsPerBlock), B);
     const int  t1 = std::min(std::max(iniTh, 0), 255), t2 = std::min(std::max(minTh, 0), 255);
-    // pyramid levels are 64-byte pitched and 256-byte based; level 0 is the caller's buffer
-    const bool al4 = (step % 4 == 0) && (frameStride % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_imgs) & 3) == 0);
     const int dbg = getenv("ORBX_DBG_SKIP_FAST") ? atoi(getenv("ORBX_DBG_SKIP_FAST")) : 0;  // ablation switch (tuning)
     // tile geometry of this image size: tiles are staged from the aligned column below iniX (up to +3 columns)
     int maxW = 0, maxH = 0;
@@ -418,7 +432,7 @@ int orbx_extractor::run(const uint8_t* d_imgs, int B, int rows, int cols, size_t
   if (overlapBlur)
     HIP_TRY(hipStreamWaitEvent(s, evJoin, 0));  // join
   else
-    hipLaunchKernelGGL(k_blur_levels, dim3(8 * ((g.totalBlurTiles + 7) / 8), B), dim3(256), 0, s, b, g);
+    launchBlur(s);
   if (prof) HIP_TRY(hipEventRecord(ev[5], s));
   {
     const int nbPerFrame = (g.totalKp + 3) / 4;

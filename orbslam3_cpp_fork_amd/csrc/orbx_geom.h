@@ -34,7 +34,7 @@ struct LevelGeom {
   float scale;              // mvScaleFactor[level]
   int   patchSize;          // (int)(PATCH_SIZE * scale)
   int   xtabOff, ytabOff;   // offsets into the resize tables (entries), valid for level >= 1
-  int   blurTileBase, blurTilesX, blurTilesY;
+  int   blurTileBase, blurTilesX, blurTilesY;  // interior work items: first workgroup of the level, 4-column groups, row strips
 };
 
 struct FrameGeom {

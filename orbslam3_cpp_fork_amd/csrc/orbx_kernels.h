@@ -14,6 +14,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "octree_core.h"
 #include "orb_sincosf_port.h"
 #include "orbx_geom.h"
@@ -689,6 +691,7 @@ __device__ __forceinline__ int reflect101(int p, int n) {
 // (4 bytes, one store) per input row.  No LDS, no second pass; neighbouring lanes' overlapping loads hit L1.
 // Work items are dealt level by level, 256 per workgroup (LevelGeom::blurTileBase counts workgroups).
 constexpr int kBlurRows = 16;
+constexpr int kBlurEdgeRows = 4;  // strip height of the edge items: few items, so short strips keep enough of them in flight
 
 // Three dwords covering columns x0-4 .. x0+7 of one row (reflect-101 at the image edges).
 __device__ __forceinline__ int reflect101_once(int p, int n) {  // valid for -n < p < 2n - 1
@@ -715,21 +718,27 @@ __device__ __forceinline__ void blur_load12(const uint8_t* __restrict__ row, int
 
 // One 4-column x kBlurRows strip.  The 7-row window of horizontal sums is a ring indexed with compile-time
 // constants (the row loop is fully unrolled), so nothing is shifted.
-template <bool FAST>
+template <bool FAST, int ROWS>
 __device__ __forceinline__ void blur_strip(const uint8_t* __restrict__ src, int pitch, uint8_t* __restrict__ dst, int dpitch, int w, int h, int x0,
                                            int y0) {
   // Q8 taps {18,34,48,56,48,34,18} as two byte vectors for v_dot4_u32_u8: window bytes p[i..i+3] and p[i+4..i+6]
   const uint32_t T0 = 18u | (34u << 8) | (48u << 16) | (56u << 24), T1 = 48u | (34u << 8) | (18u << 16);
-  uint32_t       hr[7][4];
+  // Vertical pass with v_dot2_u32_u16: the horizontal sums (<= 255 * 256, 16 bits) of rows r-1 and r are kept PACKED in
+  // one register, pr[r] = h[r-1] | h[r] << 16, so the 7-tap column sum of output row r-3 is three dot2 + one mad:
+  //   32768 + (18,34).pr[r-5] + (48,56).pr[r-3] + (48,34).pr[r-1] + 18 h[r]      (< 2^24: byte 2 is the rounded result)
+  typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+  const us2 W01 = {18, 34}, W23 = {48, 56}, W45 = {48, 34};
+  uint32_t  pr[6][4];  // ring of packed row pairs, indexed with compile-time constants (the row loop is fully unrolled)
+  uint32_t  hp[4] = {0, 0, 0, 0};
 #pragma unroll
-  for (int r = 0; r < kBlurRows + 6; r++) {
+  for (int r = 0; r < ROWS + 6; r++) {
     int sy = y0 + r - 3;  // reflect-101 rows; beyond the image bottom the strip's extra rows are never used
     sy     = sy < 0 ? -sy : sy;
     sy     = sy >= h ? max(2 * h - 2 - sy, 0) : sy;
     uint32_t a, m, c;
     blur_load12<FAST>(src + (long long)sy * pitch, x0, w, a, m, c);
     // horizontal pass: output column x0+i sees bytes (x0+i-3 .. x0+i+3); alignbyte slides the 12-byte window
-    uint32_t* hn = hr[r % 7];
+    uint32_t hn[4];
     hn[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(c, m, 1), T1, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(m, a, 1), T0, 0u, false), false);
     hn[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(c, m, 2), T1, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(m, a, 2), T0, 0u, false), false);
     hn[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(c, m, 3), T1, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(m, a, 3), T0, 0u, false), false);
@@ -737,25 +746,33 @@ __device__ __forceinline__ void blur_strip(const uint8_t* __restrict__ src, int 
     if (r >= 6) {
       const int oy = y0 + r - 6;
       if (oy < h) {
-        const uint32_t *h0 = hr[(r - 6) % 7], *h1 = hr[(r - 5) % 7], *h2 = hr[(r - 4) % 7], *h3 = hr[(r - 3) % 7], *h4 = hr[(r - 2) % 7],
-                       *h5 = hr[(r - 1) % 7], *h6 = hr[r % 7];
-        uint32_t out = 0;
+        const uint32_t *p5 = pr[(r - 5) % 6], *p3 = pr[(r - 3) % 6], *p1 = pr[(r - 1) % 6];
+        uint32_t        sv[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-          const uint32_t sacc = 18u * (h0[i] + h6[i]) + 34u * (h1[i] + h5[i]) + 48u * (h2[i] + h4[i]) + 56u * h3[i];
-          out |= ((sacc + 32768u) >> 16) << (8 * i);
+          uint32_t acc = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, p5[i]), W01, 32768u, false);
+          acc          = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, p3[i]), W23, acc, false);
+          acc          = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, p1[i]), W45, acc, false);
+          sv[i]        = acc + 18u * hn[i];
         }
+        // byte 2 of the four sums -> one dword
+        const uint32_t out = __builtin_amdgcn_perm(sv[1], sv[0], 0x0c0c0602u) | __builtin_amdgcn_perm(sv[3], sv[2], 0x06020c0cu);
         *reinterpret_cast<uint32_t*>(dst + (long long)oy * dpitch + x0) = out;
       }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      pr[r % 6][i] = hp[i] | (hn[i] << 16);
+      hp[i]        = hn[i];
     }
   }
 }
 
 // Work items of a level = (row strip, 4-column group).  Groups whose 12-byte window lies inside the row take the
-// aligned-dword path; the 2-3 edge groups of every strip need reflected byte loads.  Mixing them in one wave makes the
-// whole wave run the slow path, so the interior items are dealt first (dense waves, fast path only) and all edge
-// items of the level afterwards in workgroups of their own.  LevelGeom::blurTileBase counts workgroups.
-__global__ __launch_bounds__(256) void k_blur_levels(Bufs b, FrameGeom g) {
+// aligned-dword path (k_blur_levels: 56 registers, 8 waves per SIMD); the 2-3 edge groups of every strip need reflected
+// byte loads and live in a kernel of their own (k_blur_edges) so that their register appetite does not set the occupancy of
+// the other 98 %.  A level whose source is not 4-byte aligned (only the caller's level 0 can be) goes to the edge kernel whole.
+__global__ __launch_bounds__(256, 8) void k_blur_levels(Bufs b, FrameGeom g, int l0Aligned) {
   const int f = blockIdx.y, tid = threadIdx.x;
   int       t = xcd_item(blockIdx.x, g.totalBlurTiles), level = 0;
   if (t < 0) return;
@@ -765,23 +782,114 @@ __global__ __launch_bounds__(256) void k_blur_levels(Bufs b, FrameGeom g) {
   int            pitch;
   const uint8_t* src = level_raw(b, g, level, f, &pitch);
   uint8_t*       dst = b.blur + (long long)f * g.blurBytes + L.blurOff;
-  const bool     al4 = ((pitch & 3) == 0) && ((reinterpret_cast<uintptr_t>(src) & 3) == 0);
-  const int      groups = (L.w + 3) >> 2, strips = L.blurTilesY;
+  if (level == 0 && !l0Aligned) return;  // every group of an unaligned level 0 is an edge item
   // interior groups 1 .. gLast: x0 >= 4 and x0 + 8 <= w
-  const int gLast = (L.w - 8) >> 2, nInt = al4 ? max(gLast, 0) : 0, nEdge = groups - nInt;
-  const int intBlocks = (nInt * strips + 255) >> 8;
-  if (t < intBlocks) {
-    const int item = t * 256 + tid;
-    if (item >= nInt * strips) return;
-    const int strip = item / nInt, gi = 1 + item - strip * nInt;
-    blur_strip<true>(src, pitch, dst, L.blurPitch, L.w, L.h, gi * 4, strip * kBlurRows);
-  } else {
-    const int item = (t - intBlocks) * 256 + tid;
-    if (item >= nEdge * strips) return;
-    const int strip = item / nEdge, e = item - strip * nEdge;
-    const int gi = nInt == 0 ? e : (e == 0 ? 0 : gLast + e);  // group 0, then the trailing groups gLast+1 .. groups-1
-    blur_strip<false>(src, pitch, dst, L.blurPitch, L.w, L.h, gi * 4, strip * kBlurRows);
+  const int nInt = max((L.w - 8) >> 2, 0), strips = L.blurTilesY;
+  const int item = t * 256 + tid;
+  if (item >= nInt * strips) return;
+  const int strip = item / nInt, gi = 1 + item - strip * nInt;
+  blur_strip<true, kBlurRows>(src, pitch, dst, L.blurPitch, L.w, L.h, gi * 4, strip * kBlurRows);
+}
+
+// Edge columns of the aligned levels: the first 4 columns and the last 4-8 columns (everything from 4 * (gLast + 1) on) of
+// every row.  A lane owns one ROW: its loads stay inside the first / last cache line of that row, so every edge line is
+// fetched once (column strips re-fetch each of them for every strip that overlaps it, scattered 128-byte reads that cost
+// as much as the whole interior pass).  Horizontal sums go through LDS, then lanes switch to one OUTPUT row each.
+constexpr int kBlurEdgeOutRows = 250;  // output rows per workgroup (256 input rows with the 3 + 3 halo)
+constexpr int kBlurEdgeCols    = 12;   // 4 left + up to 8 right
+
+__host__ __device__ inline int blur_edge_blocks(const LevelGeom& L) { return (L.h + kBlurEdgeOutRows - 1) / kBlurEdgeOutRows; }
+
+__global__ __launch_bounds__(256) void k_blur_edges(Bufs b, FrameGeom g, int firstLevel) {
+  __shared__ uint32_t hs[256][kBlurEdgeCols + 1];
+  const int f = blockIdx.y, tid = threadIdx.x;
+  int       t = blockIdx.x, level = firstLevel;
+  for (;; level++) {
+    const int nb = blur_edge_blocks(g.lv[level]);
+    if (t < nb || level + 1 >= g.nlevels) break;
+    t -= nb;
   }
+  const LevelGeom& L = g.lv[level];
+  int              pitch;
+  const uint8_t*   src = level_raw(b, g, level, f, &pitch);
+  uint8_t*         dst = b.blur + (long long)f * g.blurBytes + L.blurOff;
+  const int        w = L.w, h = L.h, y0 = t * kBlurEdgeOutRows;
+  const int        xr0 = 4 * (((w - 8) >> 2) + 1), nRight = min(4 * ((w + 3) >> 2) - xr0, kBlurEdgeCols - 4);
+  {  // horizontal sums of input row y0 + tid - 3 (reflect-101): five aligned dword loads, bytes picked at compile time
+    int sy = y0 + tid - 3;
+    sy     = sy < 0 ? -sy : sy;
+    sy     = sy >= h ? max(2 * h - 2 - sy, 0) : sy;
+    const uint8_t* __restrict__ row = src + (long long)sy * pitch;
+    const int      d  = w - xr0;  // real columns right of xr0: 4 .. 7
+    const uint32_t l0 = *reinterpret_cast<const uint32_t*>(row), l1 = *reinterpret_cast<const uint32_t*>(row + 4);
+    const uint32_t r0 = *reinterpret_cast<const uint32_t*>(row + xr0 - 4), r1 = *reinterpret_cast<const uint32_t*>(row + xr0);
+    const uint32_t r2 = d > 4 ? *reinterpret_cast<const uint32_t*>(row + xr0 + 4) : 0u;  // never read past a row that ends at xr0 + 4
+    int Lb[8], Rb[12];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      Lb[i] = (l0 >> (8 * i)) & 0xff, Lb[4 + i] = (l1 >> (8 * i)) & 0xff;
+      Rb[i] = (r0 >> (8 * i)) & 0xff, Rb[4 + i] = (r1 >> (8 * i)) & 0xff, Rb[8 + i] = (r2 >> (8 * i)) & 0xff;
+    }
+    const int taps[7] = {18, 34, 48, 56, 48, 34, 18};
+#pragma unroll
+    for (int c = 0; c < 4; c++) {  // left: column -k mirrors to k
+      uint32_t acc = 0;
+#pragma unroll
+      for (int k = 0; k < 7; k++) acc += (uint32_t)(taps[k] * Lb[c + k - 3 < 0 ? 3 - c - k : c + k - 3]);
+      hs[tid][c] = acc;
+    }
+    // right: Rb[i] = column xr0 - 4 + i; column xr0 + t with t >= d mirrors to xr0 + 2 (d - 1) - t
+    auto right = [&](auto dTag) {
+      constexpr int D = decltype(dTag)::value;
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        uint32_t acc = 0;
+        if (j < D) {
+#pragma unroll
+          for (int k = 0; k < 7; k++) {
+            const int t = j + k - 3;
+            acc += (uint32_t)(taps[k] * Rb[(t < D ? t : 2 * (D - 1) - t) + 4]);
+          }
+        }
+        hs[tid][4 + j] = acc;
+      }
+    };
+    if (d == 4)
+      right(std::integral_constant<int, 4>{});
+    else if (d == 5)
+      right(std::integral_constant<int, 5>{});
+    else if (d == 6)
+      right(std::integral_constant<int, 6>{});
+    else
+      right(std::integral_constant<int, 7>{});
+  }
+  __syncthreads();
+  const int oy = y0 + tid;
+  if (tid >= kBlurEdgeOutRows || oy >= h) return;
+  uint32_t o[kBlurEdgeCols];
+#pragma unroll
+  for (int j = 0; j < kBlurEdgeCols; j++) {
+    const uint32_t sacc = 18u * (hs[tid][j] + hs[tid + 6][j]) + 34u * (hs[tid + 1][j] + hs[tid + 5][j]) + 48u * (hs[tid + 2][j] + hs[tid + 4][j]) + 56u * hs[tid + 3][j];
+    o[j]                = (sacc + 32768u) >> 16;
+  }
+  uint8_t* drow = dst + (long long)oy * L.blurPitch;
+  *reinterpret_cast<uint32_t*>(drow) = o[0] | (o[1] << 8) | (o[2] << 16) | (o[3] << 24);
+  *reinterpret_cast<uint32_t*>(drow + xr0) = o[4] | (o[5] << 8) | (o[6] << 16) | (o[7] << 24);
+  if (nRight > 4) *reinterpret_cast<uint32_t*>(drow + xr0 + 4) = o[8] | (o[9] << 8) | (o[10] << 16) | (o[11] << 24);
+}
+
+// Unaligned level 0 (the caller's buffer is not 4-byte aligned / pitched): every group takes the byte-load strip.
+__global__ __launch_bounds__(256) void k_blur_level0_bytes(Bufs b, FrameGeom g) {
+  const int        f = blockIdx.y, tid = threadIdx.x;
+  const LevelGeom& L = g.lv[0];
+  int              pitch;
+  const uint8_t*   src = level_raw(b, g, 0, f, &pitch);
+  uint8_t*         dst = b.blur + (long long)f * g.blurBytes + L.blurOff;
+  const int        groups = (L.w + 3) >> 2, strips = (L.h + kBlurEdgeRows - 1) / kBlurEdgeRows;
+  const int        item = blockIdx.x * 256 + tid;
+  if (item >= groups * strips) return;
+  const int strip = item / groups, gi = item - strip * groups;
+  blur_strip<false, kBlurEdgeRows>(src, pitch, dst, L.blurPitch, L.w, L.h, gi * 4, strip * kBlurEdgeRows);
 }
 
 // ------------------------------------------------------------------------------------------------
