@@ -97,7 +97,8 @@ struct orbx_extractor {
   DevBuf<int2>    dXtab, dYtab;
   DevBuf<int4>    dCellDesc;
   DevBuf<long long> dDbgT;
-  DevBuf<int>     dCellOrder, dCellSlot, dCellCount, dCellOffs, dCandCount, dLvlCount, dOutIdx, dCounts;
+  DevBuf<int>     dCellOrder, dCellSlot, dCellCount, dCellOffs, dCandCount, dLvlCount, dCounts;
+  DevBuf<int2>    dOutIdx;
   DevBuf<uint16_t> dNodeOf, dD, dDIndex, dPushOff, dMultiOff, dKeptRank, dVA, dVB;
   int              octLdsNodeCap = 0, octLdsPtsCap = 0, octLdsBytes = 0;  // dynamic LDS plan of k_octree (makeGeometry)
   DevBuf<uint32_t>           dSlots, dCand, dLvlKp;
@@ -501,7 +502,25 @@ int orbx_create(orbx_t** out, int nfeatures, float scale_factor, int nlevels, in
     delete h;
     return -3;
   }
-  e = hipMemcpy(h->dPattern.p, kPatternHost, 1024, hipMemcpyHostToDevice);
+  {
+    static orbx::PatternTab tab;  // rBRIEF pattern + IC_Angle dot-product weights
+    memcpy(tab.v, kPatternHost, 1024);
+    static const int umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};  // src/ORBextractor.cc:448-464
+    for (int idx = 0; idx < orbx::kMomSlots; idx++) {
+      const int v = (idx >> 3) - orbx::kHalfPatch, d = umax[v < 0 ? -v : v];
+      uint32_t  wu = 0, wv = 0, w1 = 0;
+      for (int t = 0; t < 4; t++) {
+        const int u = -orbx::kHalfPatch + (idx & 7) * 4 + t;
+        if (u >= -d && u <= d) {
+          wu |= (uint32_t)(u + orbx::kHalfPatch) << (8 * t);
+          wv |= (uint32_t)(v + orbx::kHalfPatch) << (8 * t);
+          w1 |= 1u << (8 * t);
+        }
+      }
+      tab.momW[idx][0] = wu, tab.momW[idx][1] = wv, tab.momW[idx][2] = w1;
+    }
+    e = hipMemcpy(h->dPattern.p, &tab, sizeof(tab), hipMemcpyHostToDevice);
+  }
   if (e != hipSuccess) {
     g_err = std::string("hipMemcpy(pattern): ") + hipGetErrorString(e);
     delete h;

@@ -55,7 +55,7 @@ struct Bufs {
   int*                candCount;  // [B][L]
   uint32_t*           lvlKp;      // [B][totalKp]
   int*                lvlCount;   // [B][L]
-  int*                outIdx;     // [B][totalKp]
+  int2*               outIdx;     // [B][totalKp] per keypoint in natural order: .x = packed (x, y, response), .y = level | output row << 4
 };
 
 __device__ __forceinline__ const uint8_t* level_raw(const Bufs& b, const FrameGeom& g, int level, int f, int* pitch) {
@@ -647,15 +647,18 @@ __global__ __launch_bounds__(256) void k_layout(Bufs b, FrameGeom g, int lap0, i
   }
   lbase[g.nlevels] = n;
   const uint32_t* kp  = b.lvlKp + (long long)f * g.totalKp;
-  int*            oix = b.outIdx + (long long)f * g.totalKp;
+  int2*           oix = b.outIdx + (long long)f * g.totalKp;
   int             lo, hi;
   ot_chunk(c, n, &lo, &hi);
+  uint32_t rOut = 0;
+  int      lOut = 0;
   auto pred = [&](int i) -> bool {
     int l = 0;
     while (l + 1 < g.nlevels && i >= lbase[l + 1]) l++;
     const uint32_t r  = kp[g.lv[l].kpBase + (i - lbase[l])];
     float          xs = (float)(ot_cx(r) + kMinBorder);
     if (l != 0) xs = xs * g.lv[l].scale;
+    rOut = r, lOut = l;
     return xs >= (float)lap0 && xs <= (float)lap1;
   };
   Int4 loc = {{0, 0, 0, 0}};
@@ -664,8 +667,9 @@ __global__ __launch_bounds__(256) void k_layout(Bufs b, FrameGeom g, int lap0, i
   Int4 ex     = c.scan4(loc, &tot);
   int  stereo = ex.v[0];
   for (int i = lo; i < hi; i++) {
-    const bool p = pred(i);
-    oix[i]       = p ? (n - 1 - stereo) : (i - stereo);
+    const bool p   = pred(i);
+    const int  row = p ? (n - 1 - stereo) : (i - stereo);
+    oix[i]         = make_int2((int)rOut, lOut | (row << 4));  // everything k_orient_describe needs about keypoint i, one load
     stereo += p ? 1 : 0;
   }
   if (c.tid == 0) {
@@ -895,8 +899,13 @@ __global__ __launch_bounds__(256) void k_blur_level0_bytes(Bufs b, FrameGeom g) 
 // ------------------------------------------------------------------------------------------------
 // IC_Angle (:66-91) + computeOrbDescriptor (:94-139) + output record (:1115-1134): one wave per keypoint.
 // ------------------------------------------------------------------------------------------------
+// IC_Angle weights (src/ORBextractor.cc:66-91, umax :448-464): the 31-row disc read as 31 x 8 dwords (columns u = -15 .. 16
+// of row v); for slot (v, j) three byte vectors for v_dot4_u32_u8 -- {u + 15}, {v + 15}, {1} on the bytes with |u| <= umax[|v|],
+// 0 elsewhere.  m10 = sum(u I) = dot(I, u + 15) - 15 dot(I, 1), likewise m01.
+constexpr int kMomSlots = 31 * 8;
 struct PatternTab {
   signed char v[1024];
+  uint32_t    momW[kMomSlots][3];
 };
 
 __device__ __forceinline__ float fast_atan2_deg(float y, float x) {  // cv::fastAtan2 scalar path
@@ -931,61 +940,51 @@ __global__ __launch_bounds__(256) void k_orient_describe(Bufs b, FrameGeom g, co
   const int q = blockIdx.x >> 3, f = (blockIdx.x & 7) + 8 * (q / nbPerFrame);
   if (f >= nframes) return;
   const int i = (q % nbPerFrame) * 4 + (threadIdx.x >> 6);
-  const int n = counts[2 * f];
+  // (packed candidate, level, output row) were laid down by k_layout: one load, requested together with the frame's count
+  const int  n    = counts[2 * f];
+  const int2 info = i < g.totalKp ? b.outIdx[(long long)f * g.totalKp + i] : make_int2(0, 0);
   if (i >= n) return;
-  // level of keypoint i: all level counts are fetched at once (independent loads), then a register-only search --
-  // a `while (i >= base + lc[level])` walk would be a chain of up to 8 dependent global loads per wave
-  const int* lc = b.lvlCount + (long long)f * g.nlevels;
-  int        cnts[kMaxLevels];
+  const uint32_t   r     = (uint32_t)info.x;
+  const int        level = info.y & 15, row = info.y >> 4;
+  const LevelGeom& L     = g.lv[level];
+  const int        px = ot_cx(r) + kMinBorder, py = ot_cy(r) + kMinBorder;
+  // The blurred 37 x 37 window around the keypoint only depends on (px, py): request it now, next to the moment loads
+  // below, so that the wave pays one memory round trip for both (it is short and latency-bound).
+  const int      ax  = (px - 18) & ~3;  // aligned first column; the blurred level base and pitch are 64-byte aligned
+  const uint8_t* blr = b.blur + (long long)f * g.blurBytes + L.blurOff + (long long)(py - 18) * L.blurPitch + ax;
+  uint32_t       win[7];
 #pragma unroll
-  for (int l = 0; l < kMaxLevels; l++) cnts[l] = l < g.nlevels ? lc[l] : 0;
-  const int row = b.outIdx[(long long)f * g.totalKp + i];  // output row: needed last, requested first
-  int       level = 0, base = 0;
-#pragma unroll
-  for (int l = 0; l < kMaxLevels - 1; l++) {
-    if (l + 1 < g.nlevels && i >= base + cnts[l] && level == l) {
-      base += cnts[l];
-      level = l + 1;
+  for (int k = 0; k < 7; k++) {
+    const int idx = lane + 64 * k;
+    win[k]        = 0;
+    if (idx < 37 * 11 && !(dbgSkip & 2)) {
+      const int rr = idx / 11, cc = idx - rr * 11;
+      win[k]       = *reinterpret_cast<const uint32_t*>(blr + (long long)rr * L.blurPitch + cc * 4);
     }
   }
-  const LevelGeom& L  = g.lv[level];
-  const uint32_t   r  = b.lvlKp[(long long)f * g.totalKp + L.kpBase + (i - base)];
-  const int        px = ot_cx(r) + kMinBorder, py = ot_cy(r) + kMinBorder;
   // ---- orientation on the raw level
   int            pitch;
   const uint8_t* img    = level_raw(b, g, level, f, &pitch);
   int m10 = 0, m01 = 0;
   if (!(dbgSkip & 1)) {
-    // The 31-row disc is read as 31 x 9 aligned dwords (columns ax .. ax+35 cover px-15 .. px+15): 5 independent
-    // 32-bit loads per lane instead of 16 byte loads.  umax[|v|] (src/ORBextractor.cc:448-464) is nibble-packed.
-    const unsigned long long kUmax = 0x3689ABCDDEEEFFFFull;  // nibble v = umax[v]: 15,15,15,15,14,14,14,13,13,12,11,10,9,8,6,3
-    const int                ax    = (px - kHalfPatch) & ~3;
-    const uint8_t*           rp    = img + (long long)(py - kHalfPatch) * pitch + ax;
-    const bool               al4   = ((pitch & 3) == 0) && ((reinterpret_cast<uintptr_t>(img) & 3) == 0);
+    // Lane l owns the slots l, l + 64, l + 128, l + 192 of the 31 x 8 dword grid; the pixel dword is an unaligned 32-bit
+    // load straight at (px - 15 + 4 j, py - 15 + row) and the disc mask / coordinates sit in the per-slot weight vectors.
+    const uint8_t* rp = img + (long long)(py - kHalfPatch) * pitch + (px - kHalfPatch);
+    uint32_t       su = 0, sv = 0, s1 = 0;
 #pragma unroll
-    for (int k = 0; k < 5; k++) {
+    for (int k = 0; k < 4; k++) {
       const int idx = lane + 64 * k;
-      if (idx < 31 * 9) {
-        const int      rr = idx / 9, cc = idx - rr * 9;
-        const uint8_t* p  = rp + (long long)rr * pitch + cc * 4;
+      if (idx < kMomSlots) {
+        const uint8_t* p = rp + (long long)(idx >> 3) * pitch + (idx & 7) * 4;
         uint32_t       dw;
-        if (al4) {
-          dw = *reinterpret_cast<const uint32_t*>(p);
-        } else {
-          dw = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
-        }
-        const int v  = rr - kHalfPatch;
-        const int d  = (int)((kUmax >> (4 * (v < 0 ? -v : v))) & 15ull);
-        const int u0 = ax + cc * 4 - px;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-          const int u   = u0 + j;
-          const int val = (u >= -d && u <= d) ? (int)((dw >> (8 * j)) & 0xffu) : 0;
-          m10 += u * val;
-          m01 += v * val;
-        }
+        __builtin_memcpy(&dw, p, 4);
+        su = __builtin_amdgcn_udot4(dw, pat->momW[idx][0], su, false);
+        sv = __builtin_amdgcn_udot4(dw, pat->momW[idx][1], sv, false);
+        s1 = __builtin_amdgcn_udot4(dw, pat->momW[idx][2], s1, false);
       }
     }
+    m10 = (int)su - kHalfPatch * (int)s1;
+    m01 = (int)sv - kHalfPatch * (int)s1;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
       m10 += __shfl_xor(m10, off, 64);
@@ -1004,14 +1003,12 @@ __global__ __launch_bounds__(256) void k_orient_describe(Bufs b, FrameGeom g, co
   // LDS byte reads.
   __shared__ __align__(16) uint8_t patch[4][37 * 44];
   uint8_t*       pw  = patch[threadIdx.x >> 6];
-  const int      ax  = (px - 18) & ~3;  // aligned first column; the blurred level base and pitch are 64-byte aligned
-  const uint8_t* blr = b.blur + (long long)f * g.blurBytes + L.blurOff + (long long)(py - 18) * L.blurPitch + ax;
 #pragma unroll
   for (int k = 0; k < 7; k++) {
     const int idx = lane + 64 * k;
-    if (idx < 37 * 11 && !(dbgSkip & 2)) {
+    if (idx < 37 * 11) {
       const int rr = idx / 11, cc = idx - rr * 11;
-      *reinterpret_cast<uint32_t*>(pw + rr * 44 + cc * 4) = *reinterpret_cast<const uint32_t*>(blr + (long long)rr * L.blurPitch + cc * 4);
+      *reinterpret_cast<uint32_t*>(pw + rr * 44 + cc * 4) = win[k];
     }
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // single wave: its own LDS writes are complete
