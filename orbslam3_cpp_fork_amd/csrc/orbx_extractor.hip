@@ -98,7 +98,7 @@ struct orbx_extractor {
   DevBuf<int4>    dCellDesc;
   DevBuf<long long> dDbgT;
   DevBuf<int>     dCellOrder, dCellSlot, dCellCount, dCellOffs, dCandCount, dLvlCount, dCounts;
-  DevBuf<int2>    dOutIdx;
+  DevBuf<int4>    dOutIdx;
   DevBuf<uint16_t> dNodeOf, dD, dDIndex, dPushOff, dMultiOff, dKeptRank, dVA, dVB;
   int              octLdsNodeCap = 0, octLdsPtsCap = 0, octLdsBytes = 0;  // dynamic LDS plan of k_octree (makeGeometry)
   DevBuf<uint32_t>           dSlots, dCand, dLvlKp;
@@ -330,7 +330,7 @@ int orbx_extractor::ensureWorkspace(int rows, int cols, int B) {
       dNodesA.ensure(nn) || dNodesB.ensure(nn) || dChildCnt.ensure(nn) || dChildIdx.ensure(nn) || dD.ensure(nn) ||
       dDIndex.ensure(nn) || dNCh.ensure(nn) || dPushOff.ensure(nn) || dMultiOff.ensure(nn) || dKeptRank.ensure(nn) || dVA.ensure(nn) ||
       dVB.ensure(nn) || dCandCount.ensure(nb * g.nlevels) || dLvlKp.ensure(nb * g.totalKp) ||
-      dLvlCount.ensure(nb * g.nlevels) || dOutIdx.ensure(nb * g.totalKp))
+      dLvlCount.ensure(nb * g.nlevels) || dOutIdx.ensure(2 * nb * g.totalKp))
     return -3;
   orbx::Bufs& b = bufs;
   b.pyr = dPyr.p, b.blur = dBlur.p, b.xtab = dXtab.p, b.ytab = dYtab.p, b.cellSlot = dCellSlot.p, b.cellOrder = dCellOrder.p, b.cellDesc = dCellDesc.p, b.slots = dSlots.p;
@@ -436,7 +436,7 @@ int orbx_extractor::run(const uint8_t* d_imgs, int B, int rows, int cols, size_t
     launchBlur(s);
   if (prof) HIP_TRY(hipEventRecord(ev[5], s));
   {
-    const int nbPerFrame = (g.totalKp + 3) / 4;
+    const int nbPerFrame = (g.totalKp + kOdKpPerBlock - 1) / kOdKpPerBlock;
     hipLaunchKernelGGL(k_orient_describe, dim3(8 * ((B + 7) / 8) * nbPerFrame), dim3(256), 0, s, b, g, dPattern.p, d_counts, d_kps, d_desc, cap, B,
                        nbPerFrame, getenv("ORBX_DBG_SKIP") ? atoi(getenv("ORBX_DBG_SKIP")) : 0);
   }
@@ -503,21 +503,17 @@ int orbx_create(orbx_t** out, int nfeatures, float scale_factor, int nlevels, in
     return -3;
   }
   {
-    static orbx::PatternTab tab;  // rBRIEF pattern + IC_Angle dot-product weights
+    static orbx::PatternTab tab;  // rBRIEF pattern + IC_Angle disc masks
     memcpy(tab.v, kPatternHost, 1024);
     static const int umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};  // src/ORBextractor.cc:448-464
     for (int idx = 0; idx < orbx::kMomSlots; idx++) {
       const int v = (idx >> 3) - orbx::kHalfPatch, d = umax[v < 0 ? -v : v];
-      uint32_t  wu = 0, wv = 0, w1 = 0;
+      uint32_t  m = 0;
       for (int t = 0; t < 4; t++) {
         const int u = -orbx::kHalfPatch + (idx & 7) * 4 + t;
-        if (u >= -d && u <= d) {
-          wu |= (uint32_t)(u + orbx::kHalfPatch) << (8 * t);
-          wv |= (uint32_t)(v + orbx::kHalfPatch) << (8 * t);
-          w1 |= 1u << (8 * t);
-        }
+        if (u >= -d && u <= d) m |= 0xffu << (8 * t);
       }
-      tab.momW[idx][0] = wu, tab.momW[idx][1] = wv, tab.momW[idx][2] = w1;
+      tab.momMask[idx] = m;
     }
     e = hipMemcpy(h->dPattern.p, &tab, sizeof(tab), hipMemcpyHostToDevice);
   }

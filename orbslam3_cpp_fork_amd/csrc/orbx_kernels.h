@@ -55,7 +55,11 @@ struct Bufs {
   int*                candCount;  // [B][L]
   uint32_t*           lvlKp;      // [B][totalKp]
   int*                lvlCount;   // [B][L]
-  int2*               outIdx;     // [B][totalKp] per keypoint in natural order: .x = packed (x, y, response), .y = level | output row << 4
+  // [B][totalKp][2] per keypoint in natural order, written by k_layout so that k_orient_describe needs no level tables:
+  //   [0] = {packed (x, y, response), level | output row << 4, raw pitch, blurred pitch}
+  //   [1] = {byte offset of the 31 x 31 patch origin in the raw level (from the frame's level-0 image / pyramid block),
+  //          byte offset of the aligned 37 x 44 window origin in the frame's blurred block, scale (float bits), patch size}
+  int4*               outIdx;
 };
 
 __device__ __forceinline__ const uint8_t* level_raw(const Bufs& b, const FrameGeom& g, int level, int f, int* pitch) {
@@ -647,7 +651,7 @@ __global__ __launch_bounds__(256) void k_layout(Bufs b, FrameGeom g, int lap0, i
   }
   lbase[g.nlevels] = n;
   const uint32_t* kp  = b.lvlKp + (long long)f * g.totalKp;
-  int2*           oix = b.outIdx + (long long)f * g.totalKp;
+  int4*           oix = b.outIdx + (long long)f * g.totalKp * 2;
   int             lo, hi;
   ot_chunk(c, n, &lo, &hi);
   uint32_t rOut = 0;
@@ -669,7 +673,14 @@ __global__ __launch_bounds__(256) void k_layout(Bufs b, FrameGeom g, int lap0, i
   for (int i = lo; i < hi; i++) {
     const bool p   = pred(i);
     const int  row = p ? (n - 1 - stereo) : (i - stereo);
-    oix[i]         = make_int2((int)rOut, lOut | (row << 4));  // everything k_orient_describe needs about keypoint i, one load
+    // everything k_orient_describe needs about keypoint i
+    const LevelGeom& L  = g.lv[lOut];
+    const int        px = ot_cx(rOut) + kMinBorder, py = ot_cy(rOut) + kMinBorder;
+    const int        rawPitch = lOut == 0 ? b.img0Pitch : L.pitch;
+    const int        rawOrg   = (lOut == 0 ? 0 : L.pyrOff) + (py - kHalfPatch) * rawPitch + (px - kHalfPatch);
+    const int        blurOrg  = L.blurOff + (py - 18) * L.blurPitch + ((px - 18) & ~3);
+    oix[2 * i]     = make_int4((int)rOut, lOut | (row << 4), rawPitch, L.blurPitch);
+    oix[2 * i + 1] = make_int4(rawOrg, blurOrg, __float_as_int(L.scale), L.patchSize);
     stereo += p ? 1 : 0;
   }
   if (c.tid == 0) {
@@ -899,13 +910,13 @@ __global__ __launch_bounds__(256) void k_blur_level0_bytes(Bufs b, FrameGeom g) 
 // ------------------------------------------------------------------------------------------------
 // IC_Angle (:66-91) + computeOrbDescriptor (:94-139) + output record (:1115-1134): one wave per keypoint.
 // ------------------------------------------------------------------------------------------------
-// IC_Angle weights (src/ORBextractor.cc:66-91, umax :448-464): the 31-row disc read as 31 x 8 dwords (columns u = -15 .. 16
-// of row v); for slot (v, j) three byte vectors for v_dot4_u32_u8 -- {u + 15}, {v + 15}, {1} on the bytes with |u| <= umax[|v|],
-// 0 elsewhere.  m10 = sum(u I) = dot(I, u + 15) - 15 dot(I, 1), likewise m01.
+// IC_Angle disc (src/ORBextractor.cc:66-91, umax :448-464): the 31 rows are read as 31 x 8 dwords (columns u = -15 .. 16 of
+// row v); momMask[slot] has 0xff in the bytes with |u| <= umax[|v|].  With I' = I & mask:
+//   m10 = sum(u I') = dot4(I', {u + 15}) - 15 dot4(I', {1}),   m01 = sum_v v * dot4(I', {1}).
 constexpr int kMomSlots = 31 * 8;
 struct PatternTab {
   signed char v[1024];
-  uint32_t    momW[kMomSlots][3];
+  uint32_t    momMask[kMomSlots];
 };
 
 __device__ __forceinline__ float fast_atan2_deg(float y, float x) {  // cv::fastAtan2 scalar path
@@ -932,63 +943,93 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {  // cv::fast
 
 __constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};  // src/ORBextractor.cc:448-464
 
-__global__ __launch_bounds__(256) void k_orient_describe(Bufs b, FrameGeom g, const PatternTab* __restrict__ pat, const int* counts,
+constexpr int kOdKpPerBlock = 8;  // two keypoints per wave (one per 32-lane half), four waves
+
+__global__ __launch_bounds__(256, 6) void k_orient_describe(Bufs b, FrameGeom g, const PatternTab* __restrict__ pat, const int* counts,
                                                           KpRec* kps, uint8_t* desc, int cap, int nframes, int nbPerFrame, int dbgSkip) {
   // 1-D grid with frame -> XCD affinity: all workgroups of frame f run on XCD f % 8 (blocks b, b + 8, ... share an
   // L2), so the raw + blurred levels of a frame (1.9 MB at VGA) are pulled into ONE 4-MiB L2 instead of all eight.
-  const int lane = threadIdx.x & 63;
+  // A keypoint is a short chain of dependent steps (info -> pixels -> angle -> taps), so the kernel is bound by latency x
+  // resident waves, not by arithmetic: each wave therefore carries TWO keypoints, one per 32-lane half -- the same
+  // instruction stream, twice the work in flight.
+  const int lane = threadIdx.x & 63, hl = lane & 31, half = lane >> 5;
   const int q = blockIdx.x >> 3, f = (blockIdx.x & 7) + 8 * (q / nbPerFrame);
   if (f >= nframes) return;
-  const int i = (q % nbPerFrame) * 4 + (threadIdx.x >> 6);
+  const int i = (q % nbPerFrame) * kOdKpPerBlock + (threadIdx.x >> 6) * 2 + half;
   // (packed candidate, level, output row) were laid down by k_layout: one load, requested together with the frame's count
   const int  n    = counts[2 * f];
-  const int2 info = i < g.totalKp ? b.outIdx[(long long)f * g.totalKp + i] : make_int2(0, 0);
-  if (i >= n) return;
-  const uint32_t   r     = (uint32_t)info.x;
-  const int        level = info.y & 15, row = info.y >> 4;
-  const LevelGeom& L     = g.lv[level];
-  const int        px = ot_cx(r) + kMinBorder, py = ot_cy(r) + kMinBorder;
-  // The blurred 37 x 37 window around the keypoint only depends on (px, py): request it now, next to the moment loads
-  // below, so that the wave pays one memory round trip for both (it is short and latency-bound).
-  const int      ax  = (px - 18) & ~3;  // aligned first column; the blurred level base and pitch are 64-byte aligned
-  const uint8_t* blr = b.blur + (long long)f * g.blurBytes + L.blurOff + (long long)(py - 18) * L.blurPitch + ax;
-  uint32_t       win[7];
+  int4       inf0 = make_int4(0, 0, 0, 0), inf1 = inf0;
+  if (i < g.totalKp) {
+    inf0 = b.outIdx[((long long)f * g.totalKp + i) * 2];
+    inf1 = b.outIdx[((long long)f * g.totalKp + i) * 2 + 1];
+  }
+  if (i - half >= n) return;   // both halves idle (wave-uniform)
+  const bool valid = i < n;
+  if (!valid) {  // idle half: mirror the wave's first keypoint (in-bounds addresses, results discarded)
 #pragma unroll
-  for (int k = 0; k < 7; k++) {
-    const int idx = lane + 64 * k;
-    win[k]        = 0;
-    if (idx < 37 * 11 && !(dbgSkip & 2)) {
-      const int rr = idx / 11, cc = idx - rr * 11;
-      win[k]       = *reinterpret_cast<const uint32_t*>(blr + (long long)rr * L.blurPitch + cc * 4);
+    for (int c = 0; c < 4; c++) {
+      (&inf0.x)[c] = __shfl((&inf0.x)[c], 0, 64);
+      (&inf1.x)[c] = __shfl((&inf1.x)[c], 0, 64);
     }
   }
-  // ---- orientation on the raw level
-  int            pitch;
-  const uint8_t* img    = level_raw(b, g, level, f, &pitch);
-  int m10 = 0, m01 = 0;
-  if (!(dbgSkip & 1)) {
-    // Lane l owns the slots l, l + 64, l + 128, l + 192 of the 31 x 8 dword grid; the pixel dword is an unaligned 32-bit
-    // load straight at (px - 15 + 4 j, py - 15 + row) and the disc mask / coordinates sit in the per-slot weight vectors.
-    const uint8_t* rp = img + (long long)(py - kHalfPatch) * pitch + (px - kHalfPatch);
-    uint32_t       su = 0, sv = 0, s1 = 0;
+  const uint32_t r     = (uint32_t)inf0.x;
+  const int      level = inf0.y & 15, row = inf0.y >> 4;
+  const int      px = ot_cx(r) + kMinBorder, py = ot_cy(r) + kMinBorder;
+  const int      pitch = inf0.z, blurPitch = inf0.w;
+  // The blurred 37 x 37 window around the keypoint only depends on (px, py): request it now, next to the moment loads
+  // below, so that the wave pays one memory round trip for both.
+  const int      ax  = (px - 18) & ~3;  // aligned first column; the blurred level base and pitch are 64-byte aligned
+  const uint8_t* blr = b.blur + (long long)f * g.blurBytes;  // uniform base + 32-bit lane offsets
+  uint32_t       win[13];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const int idx = lane + 64 * k;
-      if (idx < kMomSlots) {
-        const uint8_t* p = rp + (long long)(idx >> 3) * pitch + (idx & 7) * 4;
-        uint32_t       dw;
-        __builtin_memcpy(&dw, p, 4);
-        su = __builtin_amdgcn_udot4(dw, pat->momW[idx][0], su, false);
-        sv = __builtin_amdgcn_udot4(dw, pat->momW[idx][1], sv, false);
-        s1 = __builtin_amdgcn_udot4(dw, pat->momW[idx][2], s1, false);
-      }
+  for (int k = 0; k < 13; k++) {  // unconditional (clamped) loads: nothing to branch around, all 13 in flight together
+    const int idx = min(hl + 32 * k, 37 * 11 - 1);
+    const int rr = idx / 11, cc = idx - rr * 11;
+    win[k]       = *reinterpret_cast<const uint32_t*>(blr + (uint32_t)(inf1.y + rr * blurPitch + cc * 4));
+  }
+  // this half-lane's 8 pattern pairs (it tests pair w * 32 + hl in round w): requested up front as well
+  char4 taps[8];
+#pragma unroll
+  for (int w = 0; w < 8; w++) taps[w] = *reinterpret_cast<const char4*>(&pat->v[(w * 32 + hl) * 4]);
+  // ---- orientation on the raw level
+  int m10 = 0, m01 = 0;
+  {
+    // Half-lane l owns the slots l, l + 32, ... of the 31 x 8 dword grid; the pixel dword is an unaligned 32-bit load
+    // straight at (px - 15 + 4 j, py - 15 + row) and the disc mask / coordinates sit in the per-slot weight vectors.
+    const uint8_t* rp = (level == 0 ? b.img0 + (long long)f * b.img0FrameStride : b.pyr + (long long)f * g.pyrBytes) + inf1.x;
+    uint32_t       su = 0, s1 = 0;
+    int            sv = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const int      idx = min(hl + 32 * k, kMomSlots - 1);  // 248 slots = 7.75 rounds: the clamped duplicates are masked off
+      const uint32_t msk = hl + 32 * k < kMomSlots ? pat->momMask[idx] : 0u;
+      const uint8_t* p   = rp + (idx >> 3) * pitch + (idx & 7) * 4;
+      uint32_t       dw;
+      __builtin_memcpy(&dw, p, 4);
+      dw &= msk;
+      const uint32_t t1 = __builtin_amdgcn_udot4(dw, 0x01010101u, 0u, false);
+      su                = __builtin_amdgcn_udot4(dw, 0x03020100u + (uint32_t)(idx & 7) * 0x04040404u, su, false);  // bytes u + 15
+      s1 += t1;
+      sv += ((idx >> 3) - kHalfPatch) * (int)t1;
     }
     m10 = (int)su - kHalfPatch * (int)s1;
-    m01 = (int)sv - kHalfPatch * (int)s1;
+    m01 = sv;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
+    for (int off = 16; off > 0; off >>= 1) {  // within the 32-lane half
       m10 += __shfl_xor(m10, off, 64);
       m01 += __shfl_xor(m01, off, 64);
+    }
+  }
+  // The window goes to this keypoint's LDS slice as soon as it arrives (its 13 registers are free for the trigonometry
+  // below); the taps later are LDS byte reads.
+  __shared__ __align__(16) uint8_t patch[kOdKpPerBlock][37 * 44];
+  uint8_t*       pw  = patch[(threadIdx.x >> 6) * 2 + half];
+#pragma unroll
+  for (int k = 0; k < 13; k++) {
+    const int idx = hl + 32 * k;
+    if (idx < 37 * 11) {
+      const int rr = idx / 11, cc = idx - rr * 11;
+      *reinterpret_cast<uint32_t*>(pw + rr * 44 + cc * 4) = win[k];
     }
   }
   const float angle = fast_atan2_deg((float)m01, (float)m10);
@@ -998,48 +1039,35 @@ __global__ __launch_bounds__(256) void k_orient_describe(Bufs b, FrameGeom g, co
   orbport::sincosf_port<false>(angle * factorPI, &sn, &cs);
   const float    a = cs, bb = sn;
   // The 512 taps land anywhere in a 37 x 37 window; gathering them straight from global memory costs one cache-line
-  // lookup per lane per tap (the kernel was bound by the texture addresser, not by VALU or HBM).  The window is first
-  // staged into this wave's LDS slice with coalesced aligned 32-bit loads (11 dwords x 37 rows), then the taps are
-  // LDS byte reads.
-  __shared__ __align__(16) uint8_t patch[4][37 * 44];
-  uint8_t*       pw  = patch[threadIdx.x >> 6];
-#pragma unroll
-  for (int k = 0; k < 7; k++) {
-    const int idx = lane + 64 * k;
-    if (idx < 37 * 11) {
-      const int rr = idx / 11, cc = idx - rr * 11;
-      *reinterpret_cast<uint32_t*>(pw + rr * 44 + cc * 4) = win[k];
-    }
-  }
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // single wave: its own LDS writes are complete
+  // lookup per lane per tap.  The window (requested above with coalesced aligned 32-bit loads, 11 dwords x 37 rows) goes
+  // into this keypoint's LDS slice, then the taps are LDS byte reads.
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // single wave: its own LDS writes (issued before the moments) are complete
   const uint8_t* bl = pw + 18 * 44 + (px - ax);  // window centre
   const int      bp = 44;
-  unsigned long long words[4];
+  uint32_t       mine = 0;  // half-lane w < 8 ends up with descriptor word w of its keypoint
 #pragma unroll
-  for (int w = 0; w < 4; w++) {
-    const int   pair = w * 64 + lane;
-    const char4 p4   = *reinterpret_cast<const char4*>(&pat->v[pair * 4]);
+  for (int w = 0; w < 8; w++) {
+    const char4 p4 = taps[w];
     const float x0 = (float)p4.x, y0 = (float)p4.y, x1 = (float)p4.z, y1 = (float)p4.w;
     const int   r0 = __float2int_rn(x0 * bb + y0 * a), c0 = __float2int_rn(x0 * a - y0 * bb);
     const int   r1 = __float2int_rn(x1 * bb + y1 * a), c1 = __float2int_rn(x1 * a - y1 * bb);
-    const int   t0 = (dbgSkip & 4) ? r0 : bl[r0 * bp + c0], t1 = (dbgSkip & 4) ? c1 : bl[r1 * bp + c1];
-    words[w]       = __ballot(t0 < t1);
+    const int   t0 = bl[r0 * bp + c0], t1 = bl[r1 * bp + c1];
+    const unsigned long long bal = __ballot(t0 < t1);
+    const uint32_t           wv  = half ? (uint32_t)(bal >> 32) : (uint32_t)bal;
+    mine                         = hl == w ? wv : mine;
   }
   // ---- output row
-  if (row < cap) {
-    if (lane < 4) {
-      unsigned long long wv = lane == 0 ? words[0] : lane == 1 ? words[1] : lane == 2 ? words[2] : words[3];
-      *reinterpret_cast<unsigned long long*>(desc + ((long long)f * cap + row) * 32 + lane * 8) = wv;
-    }
-    if (lane == 0) {
+  if (valid && row < cap) {
+    if (hl < 8) *reinterpret_cast<uint32_t*>(desc + ((long long)f * cap + row) * 32 + hl * 4) = mine;
+    if (hl == 0) {
       KpRec k;
       k.x = (float)px;
       k.y = (float)py;
       if (level != 0) {
-        k.x = k.x * L.scale;
-        k.y = k.y * L.scale;
+        k.x = k.x * __int_as_float(inf1.z);
+        k.y = k.y * __int_as_float(inf1.z);
       }
-      k.size     = (float)L.patchSize;
+      k.size     = (float)inf1.w;
       k.angle    = angle;
       k.response = (float)ot_cr(r);
       k.octave   = level;
