@@ -158,6 +158,33 @@ int orbm_match_window(orbm_t* h, const uint8_t* d1, const orbx_keypoint_t* kp1, 
                       const orbx_keypoint_t* kp2, int n2, float* prev_matched, float min_x, float max_x, float min_y,
                       float max_y, int window, int th, float ratio, int check_ori, int* matches12);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * ORBVocabulary::transform -- DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB> as
+ * Frame::ComputeBoW uses it (src/Frame.cc:879-884), for the configuration of ORBvoc.txt (scoring L1_NORM, weighting
+ * TF_IDF).  Node i + 1 of the tree is entry i of the arrays (node 0 = root) in the order of the text file's lines
+ * (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1337-1420); words number the leaves in that order.  k <= 32.
+ * --------------------------------------------------------------------------------------------------------- */
+typedef struct orbv_vocab orbv_t;
+int         orbv_create(orbv_t** out, int k, int L, int n_nodes, const int* parent, const uint8_t* is_leaf, const uint8_t* desc32,
+                        const double* weight, int device_id);
+/* TemplatedVocabulary::loadFromTextFile (:1337-1420); blank lines are skipped (see orbx_vocab.hip). */
+int         orbv_load_text(orbv_t** out, const char* path, int device_id);
+void        orbv_destroy(orbv_t* h);
+const char* orbv_last_error(void);
+int         orbv_info(const orbv_t* h, int* k, int* L, int* n_nodes, int* n_words);
+/* transform(features, BowVector&, FeatureVector&, levelsup) (:1127-1194).  Host pointers, synchronous.  BowVector comes
+ * back as n_words (word id ascending, value) pairs, FeatureVector as n_nodes node ids (ascending) with
+ * node_off[n_nodes + 1] offsets into feat_idx (feature indices ascending inside a node).  Every output needs room for n
+ * entries (node_off: n + 1). */
+int orbv_transform(orbv_t* h, const uint8_t* desc32, int n, int levelsup, uint32_t* word_ids, double* word_vals, int* n_words,
+                   uint32_t* node_ids, int* node_off, uint32_t* feat_idx, int* n_nodes);
+/* The same for every frame of an extraction batch, device-resident: d_desc / d_counts / cap are the buffers
+ * orbx_extract_batch_device filled.  Frame f writes d_bow_words / d_bow_vals / d_fv_nodes / d_fv_feat at [f * cap ..],
+ * d_fv_off at [f * (cap + 1) ..], d_n_words[f], d_n_nodes[f].  Enqueue only. */
+int orbv_transform_batch_device(orbv_t* h, const uint8_t* d_desc, const int* d_counts, int nframes, int cap, int levelsup,
+                                uint32_t* d_bow_words, double* d_bow_vals, int* d_n_words, uint32_t* d_fv_nodes, int* d_fv_off,
+                                uint32_t* d_fv_feat, int* d_n_nodes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

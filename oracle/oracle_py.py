@@ -276,3 +276,37 @@ def stereo_matches(ex_left, ex_right, kl, dl, kr, dr, mb, mbf):
     u, d = np.zeros(len(kl), np.float32), np.zeros(len(kl), np.float32)
     n = lib().orao_stereo_matches(ex_left._h, ex_right._h, _p(kl), _p(dl), len(kl), _p(kr), _p(dr), len(kr), mb, mbf, _p(u), _p(d))
     return n, u, d
+
+
+class OracleVocabulary:
+    """ORBVocabulary (DBoW2 TemplatedVocabulary, TF_IDF / L1_NORM) restated on the CPU: transform()."""
+
+    def __init__(self, k, L, parent, is_leaf, desc, weight):
+        L_ = lib()
+        L_.orao_vocab_create.restype = C.c_void_p
+        L_.orao_vocab_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L_.orao_vocab_destroy.argtypes = [C.c_void_p]
+        L_.orao_vocab_transform.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 9
+        parent = np.ascontiguousarray(parent, np.int32)
+        is_leaf = np.ascontiguousarray(is_leaf, np.uint8)
+        desc = np.ascontiguousarray(desc, np.uint8)
+        weight = np.ascontiguousarray(weight, np.float64)
+        self._h = L_.orao_vocab_create(k, L, len(parent), _p(parent), _p(is_leaf), _p(desc), _p(weight))
+        if not self._h:
+            raise ValueError("bad vocabulary arrays")
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orao_vocab_destroy(self._h)
+            self._h = None
+
+    def transform(self, desc, levelsup=4):
+        """-> (word_ids, word_vals, node_ids, node_off, feat_idx, word_of_feat, node_of_feat)"""
+        desc = np.ascontiguousarray(desc, np.uint8)
+        n = len(desc)
+        wi, wv = np.zeros(n + 1, np.uint32), np.zeros(n + 1, np.float64)
+        ni, no, fi = np.zeros(n + 1, np.uint32), np.zeros(n + 2, np.int32), np.zeros(n + 1, np.uint32)
+        wf, nf = np.zeros(n + 1, np.uint32), np.zeros(n + 1, np.uint32)
+        nw, nn = C.c_int(0), C.c_int(0)
+        lib().orao_vocab_transform(self._h, _p(desc), n, levelsup, _p(wi), _p(wv), C.byref(nw), _p(ni), _p(no), _p(fi), C.byref(nn), _p(wf), _p(nf))
+        return wi[: nw.value], wv[: nw.value], ni[: nn.value], no[: nn.value + 1], fi[: no[nn.value]], wf[:n], nf[:n]

@@ -1172,4 +1172,125 @@ int orao_match_window(const uint8_t* d1, const orao_keypoint_t* kp1, int n1, con
   return nmatches;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// N2: DBoW2 TemplatedVocabulary<FORB::TDescriptor, FORB>::transform (TF_IDF weighting, L1_NORM scoring)
+// ------------------------------------------------------------------------------------------------
+}  // extern "C"
+
+#include <map>
+
+struct orao_vocab {
+  struct Node {  // TemplatedVocabulary.h:297-329
+    unsigned              id = 0;
+    double                weight = 0;
+    std::vector<unsigned> children;
+    unsigned              parent = 0;
+    uint8_t               descriptor[32] = {0};
+    unsigned              word_id = 0;
+    bool                  isLeaf() const { return children.empty(); }
+  };
+  int               m_k = 0, m_L = 0;
+  std::vector<Node> m_nodes;
+  unsigned          n_words = 0;
+};
+
+extern "C" {
+
+orao_vocab_t* orao_vocab_create(int k, int L, int n_nodes, const int* parent, const uint8_t* is_leaf, const uint8_t* desc32,
+                                const double* weight) {
+  if (k <= 0 || L <= 0 || n_nodes < 0) return nullptr;
+  orao_vocab* v = new orao_vocab();
+  v->m_k = k, v->m_L = L;
+  v->m_nodes.resize(1);  // root (loadFromTextFile :1372-1373)
+  for (int i = 0; i < n_nodes; i++) {
+    const unsigned nid = (unsigned)v->m_nodes.size();  // :1381-1383
+    v->m_nodes.resize(nid + 1);
+    v->m_nodes[nid].id = nid;
+    const int pid = parent[i];
+    if (pid < 0 || (unsigned)pid >= nid) {  // the text format lists a parent before its children
+      delete v;
+      return nullptr;
+    }
+    v->m_nodes[nid].parent = (unsigned)pid;  // :1385-1388
+    v->m_nodes[(unsigned)pid].children.push_back(nid);
+    memcpy(v->m_nodes[nid].descriptor, desc32 + (size_t)i * 32, 32);  // :1393-1401
+    v->m_nodes[nid].weight = weight[i];                                 // :1403
+    if (is_leaf[i]) v->m_nodes[nid].word_id = v->n_words++;             // :1405-1411
+  }
+  return v;
+}
+
+void orao_vocab_destroy(orao_vocab_t* v) { delete v; }
+
+int orao_vocab_transform(const orao_vocab_t* voc, const uint8_t* desc32, int n, int levelsup, uint32_t* word_ids, double* word_vals,
+                         int* n_words, uint32_t* node_ids, int* node_off, uint32_t* feat_idx, int* n_nodes_out,
+                         uint32_t* word_of_feat, uint32_t* node_of_feat) {
+  std::map<unsigned, double>                v;   // BowVector
+  std::map<unsigned, std::vector<unsigned>> fv;  // FeatureVector
+  *n_words = 0, *n_nodes_out = 0;
+  if (!voc || voc->m_nodes.size() <= 1) return 0;  // empty() (:1138-1141)
+  const auto& nodes = voc->m_nodes;
+  for (int i_feature = 0; i_feature < n; i_feature++) {  // TF_IDF branch (:1149-1166)
+    const uint8_t* feature = desc32 + (size_t)i_feature * 32;
+    // transform(feature, id, w, &nid, levelsup) (:1218-1259)
+    const int nid_level = voc->m_L - levelsup;
+    unsigned  nid = 0;  // "if (nid_level <= 0) *nid = 0" -- also the value kept if the level is never reached
+    unsigned  final_id = 0;
+    int       current_level = 0;
+    do {
+      ++current_level;
+      const std::vector<unsigned>& ch = nodes[final_id].children;
+      final_id      = ch[0];
+      double best_d = (double)orao_hamming(feature, nodes[final_id].descriptor);
+      for (size_t c = 1; c < ch.size(); c++) {
+        const unsigned id = ch[c];
+        const double   d  = (double)orao_hamming(feature, nodes[id].descriptor);
+        if (d < best_d) {
+          best_d   = d;
+          final_id = id;
+        }
+      }
+      if (current_level == nid_level) nid = final_id;
+    } while (!nodes[final_id].isLeaf());
+    const unsigned id = nodes[final_id].word_id;
+    const double   w  = nodes[final_id].weight;
+    if (word_of_feat) word_of_feat[i_feature] = id;
+    if (node_of_feat) node_of_feat[i_feature] = nid;
+    if (w > 0) {  // not stopped (:1161-1165)
+      // BowVector::addWeight (BowVector.cpp:34-46)
+      auto vit = v.lower_bound(id);
+      if (vit != v.end() && !(v.key_comp()(id, vit->first)))
+        vit->second += w;
+      else
+        v.insert(vit, std::make_pair(id, w));
+      // FeatureVector::addFeature (FeatureVector.cpp:34-49)
+      auto fit = fv.lower_bound(nid);
+      if (fit != fv.end() && fit->first == nid)
+        fit->second.push_back((unsigned)i_feature);
+      else {
+        fit = fv.insert(fit, std::make_pair(nid, std::vector<unsigned>()));
+        fit->second.push_back((unsigned)i_feature);
+      }
+    }
+  }
+  // must == true for L1_NORM: v.normalize(L1) (:1191; BowVector.cpp:62-84)
+  double norm = 0.0;
+  for (auto it = v.begin(); it != v.end(); ++it) norm += fabs(it->second);
+  if (norm > 0.0)
+    for (auto it = v.begin(); it != v.end(); ++it) it->second /= norm;
+  int k = 0;
+  for (auto it = v.begin(); it != v.end(); ++it, ++k) word_ids[k] = it->first, word_vals[k] = it->second;
+  *n_words = k;
+  int m = 0, o = 0;
+  for (auto it = fv.begin(); it != fv.end(); ++it, ++m) {
+    node_ids[m] = it->first;
+    node_off[m] = o;
+    for (unsigned f : it->second) feat_idx[o++] = f;
+  }
+  node_off[m]  = o;
+  *n_nodes_out = m;
+  return 0;
+}
+
 }  // extern "C"

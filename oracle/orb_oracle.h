@@ -108,6 +108,23 @@ int orao_match_window(const uint8_t* d1, const orao_keypoint_t* kp1, int n1, con
                       const orao_keypoint_t* kp2, int n2, float* prev_matched, float min_x, float max_x, float min_y,
                       float max_y, int window, int th, float ratio, int check_ori, int* matches12);
 
+/* ---- DBoW2 vocabulary tree: ORBVocabulary::transform (N2) ----
+ * TemplatedVocabulary<FORB::TDescriptor, FORB> restated for the configuration ORB-SLAM3 ships (ORBvoc.txt header
+ * "10 6 0 0": scoring L1_NORM, weighting TF_IDF).  Node i + 1 of the tree is entry i of the arrays (node 0 = root), in the
+ * order of the lines of the text format (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1337-1420: "parent isLeaf 32 bytes
+ * weight"); word ids number the leaves in that order (:1402-1409). */
+typedef struct orao_vocab orao_vocab_t;
+orao_vocab_t* orao_vocab_create(int k, int L, int n_nodes, const int* parent, const uint8_t* is_leaf, const uint8_t* desc32,
+                                const double* weight);
+void          orao_vocab_destroy(orao_vocab_t*);
+/* transform(features, BowVector&, FeatureVector&, levelsup) (TemplatedVocabulary.h:1127-1194, single-feature descent
+ * :1218-1259; BowVector::addWeight / normalize(L1), BowVector.cpp:34-78; FeatureVector::addFeature, FeatureVector.cpp:34-49).
+ * Outputs: BowVector as (word id ascending, value); FeatureVector as node ids ascending with node_off[n_nodes_out + 1]
+ * offsets into feat_idx.  word_of_feat / node_of_feat (may be NULL): per-feature descent result. Returns 0. */
+int orao_vocab_transform(const orao_vocab_t*, const uint8_t* desc32, int n, int levelsup, uint32_t* word_ids, double* word_vals,
+                         int* n_words, uint32_t* node_ids, int* node_off, uint32_t* feat_idx, int* n_nodes_out,
+                         uint32_t* word_of_feat, uint32_t* node_of_feat);
+
 #ifdef __cplusplus
 }
 #endif

@@ -51,6 +51,13 @@ SIGNATURES = {
     "orbm_match_pairs_device": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _f, _i, _vp, _vp, _vp]),
     "orbm_debug_counters": (_i, [_vp, _i, _vp]),
     "orbm_match_window": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _f, _f, _f, _f, _i, _i, _f, _i, _vp]),
+    "orbv_create": (_i, [C.POINTER(_vp), _i, _i, _i, _vp, _vp, _vp, _vp, _i]),
+    "orbv_load_text": (_i, [C.POINTER(_vp), C.c_char_p, _i]),
+    "orbv_destroy": (None, [_vp]),
+    "orbv_last_error": (C.c_char_p, []),
+    "orbv_info": (_i, [_vp, _ip, _ip, _ip, _ip]),
+    "orbv_transform": (_i, [_vp, _vp, _i, _i, _vp, _vp, _ip, _vp, _vp, _vp, _ip]),
+    "orbv_transform_batch_device": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
 # debug hooks that run host builds of the shared host/device cores (no GPU needed)
 HOST_MODEL_SIGNATURES = {

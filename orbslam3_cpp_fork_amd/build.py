@@ -9,7 +9,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "liborbx.so")
-HIP_SOURCES = ["orbx_extractor.hip", "orbx_matcher.hip"]
+HIP_SOURCES = ["orbx_extractor.hip", "orbx_matcher.hip", "orbx_vocab.hip"]
 HOST_SOURCES = ["orbx_hostmodel.cpp"]
 HEADERS = ["orbx_kernels.h", "orbx_geom.h", "octree_core.h", "orb_sincosf_port.h", "orb_pattern.inc", "../../include/orbx.h"]
 # -ffp-contract=off: float expressions must evaluate as the reference writes them (no FMA fusion).

@@ -127,3 +127,48 @@ def planted_descriptors(train, seed, max_flips=60):
         for b in bits:
             q[i, b >> 3] ^= np.uint8(1 << (b & 7))
     return q
+
+
+def make_vocabulary(k=10, L=6, seed=7, flips=40, stop_frac=0.02, prune_frac=0.0):
+    """Synthetic DBoW2 vocabulary tree in the order of the ORBvoc.txt lines (ORBvoc.txt itself is not in the repo).
+
+    Returns (parent[int32], is_leaf[uint8], desc[n,32 uint8], weight[float64]) for nodes 1..n (node 0 is the root), breadth
+    first, so every parent precedes its children.  A child's descriptor is its parent's with ~`flips / level` random bit
+    flips (the root's children are random), which makes the greedy descent meaningful; leaves carry an idf-like positive
+    weight, `stop_frac` of them weight 0 (stopped words, skipped by transform()); `prune_frac` of the nodes of level L - 1
+    have no children and are (shallower) words, as k-means vocabularies have when a cluster runs dry.
+    """
+    rng = np.random.Generator(np.random.PCG64(seed))
+    parents, leaves, descs, weights = [], [], [], []
+    front_ids = np.zeros(1, np.int64)  # node ids of the inner nodes of the previous level
+    front_desc = None
+    next_id = 1
+    for level in range(1, L + 1):
+        m = len(front_ids) * k
+        if m == 0:
+            break
+        pid = np.repeat(front_ids, k)
+        if front_desc is None:
+            d = rng.integers(0, 256, (m, 32), dtype=np.uint8)
+        else:
+            bits = np.unpackbits(np.repeat(front_desc, k, axis=0), axis=1)
+            nf = max(1, flips // level)
+            pos = rng.integers(0, 256, (m, nf))
+            np.bitwise_xor.at(bits, (np.repeat(np.arange(m), nf), pos.ravel()), 1)
+            d = np.packbits(bits, axis=1)
+        leaf = np.ones(m, bool) if level == L else ((rng.random(m) < prune_frac) if level == L - 1 else np.zeros(m, bool))
+        w = np.where(leaf, np.where(rng.random(m) < stop_frac, 0.0, rng.uniform(0.5, 12.0, m)), 0.0)
+        ids = next_id + np.arange(m)
+        next_id += m
+        parents.append(pid), leaves.append(leaf), descs.append(d), weights.append(w)
+        front_ids, front_desc = ids[~leaf], d[~leaf]
+    return (np.concatenate(parents).astype(np.int32), np.concatenate(leaves).astype(np.uint8), np.concatenate(descs).astype(np.uint8),
+            np.concatenate(weights).astype(np.float64))
+
+
+def write_vocabulary_text(path, k, L, parent, is_leaf, desc, weight):
+    """ORBvoc.txt format (TemplatedVocabulary::saveToTextFile): header "k L scoring weighting", one node per line."""
+    with open(path, "w") as f:
+        f.write("%d %d  0 0\n" % (k, L))
+        for i in range(len(parent)):
+            f.write("%d %d %s %r\n" % (parent[i], is_leaf[i], " ".join(str(int(b)) for b in desc[i]), float(weight[i])))

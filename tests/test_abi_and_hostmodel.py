@@ -16,7 +16,7 @@ def test_header_symbols_exported():
     L = _lib.lib()
     hdr = open(os.path.join(ROOT, "include", "orbx.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    names = set(re.findall(r"\b(orb[xm]_[a-z0-9_]+)\s*\(", hdr))
+    names = set(re.findall(r"\b(orb[xmv]_[a-z0-9_]+)\s*\(", hdr))
     assert len(names) >= 20
     for n in sorted(names):
         assert hasattr(L, n), "liborbx.so does not export %s" % n

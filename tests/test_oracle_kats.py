@@ -340,3 +340,43 @@ def test_matcher_kats(oracle):
     q = np.vstack([t[7], t[7]])
     n, mq, mt = oracle.match_groups(q, t, check_ori=False, ratio=0.9)
     assert mq[0] == 7 and mq[1] == -1 and n == 1
+
+
+def _tiny_vocab():
+    """k = 2, L = 2, breadth first: nodes 1, 2 under the root; 3, 4 under 1; 5, 6 under 2.  Words: 3 -> 0, 4 -> 1, 5 -> 2
+    (stopped, weight 0), 6 -> 3."""
+    z, o = np.zeros(32, np.uint8), np.full(32, 0xFF, np.uint8)
+    n4 = z.copy()
+    n4[0] = 0x0F
+    n6 = o.copy()
+    n6[0] = 0xF0
+    parent = [0, 0, 1, 1, 2, 2]
+    leaf = [0, 0, 1, 1, 1, 1]
+    desc = np.stack([z, o, z, n4, o, n6])
+    weight = [0.0, 0.0, 1.0, 2.0, 0.0, 4.0]
+    f2 = z.copy()
+    f2[0] = 0x0F
+    f4 = z.copy()
+    f4[:16] = 0xFF  # 128 bits from node 1 and from node 2: the first child wins; then node 3 at 128, node 4 at 124
+    feats = np.stack([z, o, f2, z, f4])
+    return 2, 2, parent, leaf, desc, weight, feats
+
+
+def test_vocabulary_transform_kat(oracle):
+    """DBoW2 transform (TemplatedVocabulary.h:1127-1259) on a hand-made tree: descent with first-child tie break, stopped word,
+    TF-IDF accumulation in feature order, L1 normalisation, FeatureVector at level L - levelsup."""
+    k, L, parent, leaf, desc, weight, feats = _tiny_vocab()
+    v = oracle.OracleVocabulary(k, L, parent, leaf, desc, weight)
+    wi, wv, ni, no, fi, wf, nf = v.transform(feats, levelsup=1)
+    assert wf.tolist() == [0, 2, 1, 0, 1]
+    assert wi.tolist() == [0, 1]
+    assert wv.tolist() == [2.0 / 6.0, 4.0 / 6.0]
+    assert ni.tolist() == [1] and no.tolist() == [0, 4] and fi.tolist() == [0, 2, 3, 4]  # feature 1 fell into a stopped word
+    _, _, ni, no, fi, _, _ = v.transform(feats, levelsup=2)  # level 0: the root
+    assert ni.tolist() == [0] and fi.tolist() == [0, 2, 3, 4]
+    _, _, ni, no, fi, _, _ = v.transform(feats, levelsup=0)  # the leaves themselves
+    assert ni.tolist() == [3, 4] and no.tolist() == [0, 2, 4] and fi.tolist() == [0, 3, 2, 4]
+    # repeated addition is what the reference does: 3 x 0.1 summed, not 0.3
+    v2 = oracle.OracleVocabulary(1, 1, [0], [1], np.zeros((1, 32), np.uint8), [0.1])
+    wi, wv, *_ = v2.transform(np.zeros((3, 32), np.uint8), levelsup=0)
+    assert wv.tolist() == [(0.1 + 0.1 + 0.1) / abs(0.1 + 0.1 + 0.1)]
