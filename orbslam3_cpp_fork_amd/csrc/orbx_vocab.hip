@@ -121,11 +121,12 @@ __global__ __launch_bounds__(256) void k_bow_descend(VocabDev v, const uint8_t* 
   }
 }
 
-// One workgroup per frame.  Ranks by counting (n is ~1000: n^2 / 256 compares per thread), so no sort is needed:
+// Fallback for frames with more than 4096 features (the sorted form below needs them in LDS): ranks by counting, O(n^2).
+// One workgroup per frame:
 //   word heads  = first feature of every distinct word  -> BowVector entries, position = number of smaller distinct words
 //   valid feats = features of non-stopped words         -> FeatureVector payload, position = rank of (node, feature index)
 //   node heads  = first feature of every distinct node  -> FeatureVector keys, offset = payload position of that feature
-__global__ __launch_bounds__(256) void k_bow_build(const int* __restrict__ counts, int cap, const uint32_t* __restrict__ featWord,
+__global__ __launch_bounds__(256) void k_bow_build_counting(const int* __restrict__ counts, int cap, const uint32_t* __restrict__ featWord,
                                                    const uint32_t* __restrict__ featNode, const double* __restrict__ featW,
                                                    uint8_t* __restrict__ headFlags, double* __restrict__ parkVal, int* __restrict__ parkOff,
                                                    uint32_t* __restrict__ bowWords,
@@ -212,6 +213,123 @@ __global__ __launch_bounds__(256) void k_bow_build(const int* __restrict__ count
   const double norm = sNorm;
   if (norm > 0.0)
     for (int k = tid; k < nw; k += 256) bowVals[(size_t)f * cap + k] /= norm;
+}
+
+
+// ---- sorted form: one workgroup per frame, everything in LDS -------------------------------------------------------------
+__device__ __forceinline__ int block_excl_scan(int v, int* lds /* >= 8 ints */, int* total) {  // 256 threads
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int       inc  = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += t;
+  }
+  __syncthreads();
+  if (lane == 63) lds[wave] = inc;
+  __syncthreads();
+  int base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < 4; w++) {
+    const int t = lds[w];
+    base += w < wave ? t : 0;
+    tot += t;
+  }
+  *total = tot;
+  return base + inc - v;
+}
+
+// Ascending bitonic sort of NP (power of two) 64-bit keys in LDS by 256 threads.
+__device__ __forceinline__ void block_bitonic_sort(unsigned long long* key, int NP) {
+  for (int k = 2; k <= NP; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      __syncthreads();
+      for (int t = threadIdx.x; t < (NP >> 1); t += 256) {
+        const int  lo = 2 * t - (t & (j - 1)), hi = lo + j;  // pair (lo, lo + j) of step j
+        const bool up = (lo & k) == 0;
+        const unsigned long long a = key[lo], b = key[hi];
+        if ((a > b) == up) key[lo] = b, key[hi] = a;
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// Sort (id << 32 | feature index) of the frame's non-stopped features; equal ids end up adjacent and in feature order, which
+// is the order of the std::map<id, ...> walks of the reference.  `select` picks the id array (words, then nodes).
+// headPos (LDS, NP + 1 ints) receives the sorted position of the first feature of every distinct id; returns their number.
+__device__ __forceinline__ int sort_and_heads(unsigned long long* key, int* headPos, int* scanLds, int NP, int n, const uint32_t* W,
+                                              const uint32_t* ids, int* nValid) {
+  for (int p = threadIdx.x; p < NP; p += 256) key[p] = (p < n && W[p] != kStopped) ? (((unsigned long long)ids[p] << 32) | (unsigned)p) : ~0ull;
+  block_bitonic_sort(key, NP);
+  // heads, in chunks of contiguous positions per thread so that the scan yields ranks in position order
+  const int per = NP >> 8;  // positions per thread (NP >= 256)
+  const int p0  = threadIdx.x * per;
+  int       loc = 0, val = 0;
+  for (int p = p0; p < p0 + per; p++) {
+    const bool live = key[p] != ~0ull;
+    val += live;
+    loc += live && (p == 0 || (uint32_t)(key[p] >> 32) != (uint32_t)(key[p - 1] >> 32));
+  }
+  int       nHeads, nv;
+  int       rank = block_excl_scan(loc, scanLds, &nHeads);
+  (void)block_excl_scan(val, scanLds, &nv);
+  for (int p = p0; p < p0 + per; p++) {
+    const bool live = key[p] != ~0ull;
+    if (live && (p == 0 || (uint32_t)(key[p] >> 32) != (uint32_t)(key[p - 1] >> 32))) headPos[rank++] = p;
+  }
+  if (threadIdx.x == 0) headPos[nHeads] = nv;
+  __syncthreads();
+  *nValid = nv;
+  return nHeads;
+}
+
+__global__ __launch_bounds__(256) void k_bow_build(const int* __restrict__ counts, int cap, int NP, const uint32_t* __restrict__ featWord,
+                                                   const uint32_t* __restrict__ featNode, const double* __restrict__ featW,
+                                                   uint32_t* __restrict__ bowWords, double* __restrict__ bowVals, int* __restrict__ nWords,
+                                                   uint32_t* __restrict__ fvNodes, int* __restrict__ fvOff, uint32_t* __restrict__ fvFeat,
+                                                   int* __restrict__ nNodes) {
+  extern __shared__ __align__(16) unsigned char bowLds[];
+  unsigned long long* key     = reinterpret_cast<unsigned long long*>(bowLds);
+  int*                headPos = reinterpret_cast<int*>(bowLds + (size_t)NP * 8);
+  __shared__ int      scanLds[8];
+  __shared__ double   sNorm;
+  const int           f = blockIdx.x, tid = threadIdx.x;
+  const int           n = min(counts ? counts[2 * f] : cap, NP);
+  const uint32_t*     W = featWord + (size_t)f * cap;
+  const uint32_t*     N = featNode + (size_t)f * cap;
+  // ---- BowVector: distinct words ascending; value = the word's weight added once per feature, in feature order
+  int       nv;
+  const int nw = sort_and_heads(key, headPos, scanLds, NP, n, W, W, &nv);
+  for (int r = tid; r < nw; r += 256) {
+    const int                p   = headPos[r], cnt = headPos[r + 1] - p;
+    const unsigned long long kk  = key[p];
+    const double             w   = featW[(size_t)f * cap + (uint32_t)kk];
+    double                   sum = w;  // BowVector::addWeight: the first feature inserts w, each later one adds w (:34-46)
+    for (int t = 1; t < cnt; t++) sum += w;
+    bowWords[(size_t)f * cap + r] = (uint32_t)(kk >> 32);
+    bowVals[(size_t)f * cap + r]  = sum;
+  }
+  __threadfence_block();
+  __syncthreads();
+  if (tid == 0) {  // BowVector::normalize(L1): summed in ascending word order by one thread (:62-84)
+    double norm = 0.0;
+    for (int r = 0; r < nw; r++) norm += fabs(bowVals[(size_t)f * cap + r]);
+    sNorm     = norm;
+    nWords[f] = nw;
+  }
+  __syncthreads();
+  const double norm = sNorm;
+  if (norm > 0.0)
+    for (int r = tid; r < nw; r += 256) bowVals[(size_t)f * cap + r] /= norm;
+  // ---- FeatureVector: features sorted by (node, index) are the payload; the first of every node gives key and offset
+  const int nn = sort_and_heads(key, headPos, scanLds, NP, n, W, N, &nv);
+  for (int p = tid; p < nv; p += 256) fvFeat[(size_t)f * cap + p] = (uint32_t)key[p];
+  for (int r = tid; r <= nn; r += 256) {
+    fvOff[(size_t)f * (cap + 1) + r] = headPos[r];
+    if (r < nn) fvNodes[(size_t)f * cap + r] = (uint32_t)(key[headPos[r]] >> 32);
+  }
+  if (tid == 0) nNodes[f] = nn;
 }
 
 }  // namespace
@@ -416,8 +534,15 @@ int orbv_transform_batch_device(orbv_t* h, const uint8_t* d_desc, const int* d_c
   }
   hipLaunchKernelGGL(k_bow_descend, dim3((cap + 7) / 8, nframes), dim3(256), 0, s, h->dev, d_desc, d_counts, cap, levelsup, h->wFeatWord.p,
                      h->wFeatNode.p, h->wFeatW.p);
-  hipLaunchKernelGGL(k_bow_build, dim3(nframes), dim3(256), 0, s, d_counts, cap, h->wFeatWord.p, h->wFeatNode.p, h->wFeatW.p, h->wHead.p,
-                     h->wParkVal.p, h->wParkOff.p, d_bow_words, d_bow_vals, d_n_words, d_fv_nodes, d_fv_off, d_fv_feat, d_n_nodes);
+  int NP = 256;
+  while (NP < cap) NP <<= 1;
+  if (NP <= 4096) {  // sorted form: keys + head positions in LDS (12 bytes per slot)
+    hipLaunchKernelGGL(k_bow_build, dim3(nframes), dim3(256), (size_t)NP * 12 + 16, s, d_counts, cap, NP, h->wFeatWord.p, h->wFeatNode.p,
+                       h->wFeatW.p, d_bow_words, d_bow_vals, d_n_words, d_fv_nodes, d_fv_off, d_fv_feat, d_n_nodes);
+  } else {
+    hipLaunchKernelGGL(k_bow_build_counting, dim3(nframes), dim3(256), 0, s, d_counts, cap, h->wFeatWord.p, h->wFeatNode.p, h->wFeatW.p,
+                       h->wHead.p, h->wParkVal.p, h->wParkOff.p, d_bow_words, d_bow_vals, d_n_words, d_fv_nodes, d_fv_off, d_fv_feat, d_n_nodes);
+  }
   HIP_TRYV(hipGetLastError());
   return 0;
 }

@@ -44,10 +44,16 @@ class ORBVocabulary:
         _check(_lib.lib().orbv_create(C.byref(h), k, L, len(parent), _lib.ptr(parent), _lib.ptr(is_leaf), _lib.ptr(desc), _lib.ptr(weight), device), "orbv_create")
         return cls(_handle=h)
 
-    def __del__(self):
+    def close(self):
         if getattr(self, "_h", None):
             _lib.lib().orbv_destroy(self._h)
             self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # interpreter shutdown: the module globals may already be gone
+            pass
 
     def info(self):
         k, L, n, w = C.c_int(), C.c_int(), C.c_int(), C.c_int()

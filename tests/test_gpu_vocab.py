@@ -27,7 +27,7 @@ def test_vocab_kat(oracle):
     assert len(wi) == 0 and len(ni) == 0
 
 
-@pytest.mark.parametrize("k,L,n,levelsup", [(10, 4, 1500, 2), (10, 3, 700, 1), (7, 5, 2500, 4), (20, 3, 300, 3), (10, 6, 1000, 4)])
+@pytest.mark.parametrize("k,L,n,levelsup", [(10, 4, 1500, 2), (10, 3, 700, 1), (7, 5, 2500, 4), (20, 3, 300, 3), (10, 6, 1000, 4), (10, 4, 256, 2), (10, 4, 257, 2), (10, 4, 4096, 2), (10, 4, 5000, 2)])
 def test_vocab_random_trees(oracle, k, L, n, levelsup):
     from orbslam3_cpp_fork_amd import synth
     from orbslam3_cpp_fork_amd.vocabulary import ORBVocabulary
