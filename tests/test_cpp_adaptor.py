@@ -35,7 +35,12 @@ def test_adaptor_matches_oracle(tmp_path, oracle):
     fa, fb, out = (str(tmp_path / n) for n in ("a.raw", "b.raw", "out.txt"))
     frames[0].tofile(fa)
     frames[1].tofile(fb)
-    subprocess.check_call([exe, "480", "640", fa, fb, out], timeout=300)
+    from orbslam3_cpp_fork_amd.matcher import flatten_feature_vectors
+
+    voc = synth.make_vocabulary(10, 3, seed=21)
+    vpath = str(tmp_path / "voc.txt")
+    synth.write_vocabulary_text(vpath, 10, 3, *voc)
+    subprocess.check_call([exe, "480", "640", fa, fb, out, vpath], timeout=300)
     lines = open(out).read().split("\n")
     hdr = lines[0].split()
     oex = oracle.OracleExtractor(1000, 1.2, 8, 20, 7)
@@ -50,3 +55,21 @@ def test_adaptor_matches_oracle(tmp_path, oracle):
         assert [int(x) for x in v[5:37]] == dA[i].tolist()
     got = [int(x) for x in lines[1 + len(kA): 1 + len(kA) + len(kB)]]
     assert got == mt.tolist()
+    # ORBVocabulary adaptor: BowVector (doubles printed with %a), FeatureVector, SearchByBoW over its groups
+    ov = oracle.OracleVocabulary(10, 3, *voc)
+    wiA, wvA, niA, noA, fiA, _, _ = ov.transform(dA, 1)
+    _, _, niB, noB, fiB, _, _ = ov.transform(dB, 1)
+    base = 1 + len(kA) + len(kB)
+    h2 = lines[base].split()
+    fvA = {int(niA[i]): fiA[noA[i] : noA[i + 1]].tolist() for i in range(len(niA))}
+    fvB = {int(niB[i]): fiB[noB[i] : noB[i + 1]].tolist() for i in range(len(niB))}
+    n2, _, mt2 = oracle.match_groups(dA, dB, kA["angle"], kB["angle"], 50, 0.7, False, True, flatten_feature_vectors(fvA, fvB))
+    assert [int(x) for x in h2] == [int(voc[1].sum()), len(wiA), len(niA), len(niB), n2]
+    for i in range(len(wiA)):
+        w, v = lines[base + 1 + i].split()
+        assert int(w) == int(wiA[i]) and float.fromhex(v) == float(wvA[i])
+    for i in range(len(niA)):
+        v = [int(x) for x in lines[base + 1 + len(wiA) + i].split()]
+        assert v[0] == int(niA[i]) and v[1:] == fvA[int(niA[i])]
+    b3 = base + 1 + len(wiA) + len(niA)
+    assert [int(x) for x in lines[b3 : b3 + len(kB)]] == mt2.tolist()
