@@ -78,7 +78,7 @@ __device__ __forceinline__ const uint8_t* level_raw(const Bufs& b, const FrameGe
 // ------------------------------------------------------------------------------------------------
 // Workgroup = 128 x 16 destination tile.  The source footprint (<= 160 x 24 px at scale 1.2) is staged in LDS
 // with aligned 32-bit loads, then every thread produces 2 rows x 4 px from LDS bytes.
-constexpr int kRsTileW = 128, kRsTileH = 16, kRsLdsW = 176, kRsLdsH = 24;
+constexpr int kRsTileW = 128, kRsTileH = 16, kRsLdsW = 176, kRsLdsH = 25;  // one spare LDS row: see the vertical tap below
 
 __global__ __launch_bounds__(256) void k_resize_level(Bufs b, FrameGeom g, int level) {
   __shared__ __align__(16) uint8_t src[kRsLdsH][kRsLdsW];
@@ -96,24 +96,40 @@ __global__ __launch_bounds__(256) void k_resize_level(Bufs b, FrameGeom g, int l
   const int syb = min(max(b.ytab[L.ytabOff + dyl].x + 1, 0), Ls.h - 1);
   const int nw4 = (sxb - sxa + 4) >> 2, nrow = syb - sya + 1;  // <= 44 dwords x 24 rows
   const bool al4 = ((sp & 3) == 0) && ((reinterpret_cast<uintptr_t>(S) & 3) == 0);
-  for (int idx = tid; idx < nw4 * nrow; idx += 256) {
-    const int      r = idx / nw4, c = (idx - r * nw4) * 4;
-    const uint8_t* p = S + (long long)(sya + r) * sp + sxa + c;
-    uint32_t       v;
+  {  // staging: thread = (dword column tid % 64; rows tid / 64, +4, ...): no index division.  The loads are unconditional
+     // (clamped to the footprint) so that all six are in flight together; only the LDS stores are predicated.
+    const bool colIn = (tid & 63) < nw4;
+    const int  c     = min(tid & 63, nw4 - 1) * 4;
+    uint32_t   v[6];  // nrow <= 24 = 6 rounds of 4 rows
     if (al4) {
-      v = *reinterpret_cast<const uint32_t*>(p);  // may run past Ls.w inside the padded/aligned row: unused bytes
-    } else {
-      v = 0;
 #pragma unroll
-      for (int k = 0; k < 4; k++)
-        if (sxa + c + k < Ls.w) v |= (uint32_t)p[k] << (8 * k);
+      for (int it = 0; it < 6; it++) {
+        const int r = min((tid >> 6) + 4 * it, nrow - 1);
+        v[it]       = *reinterpret_cast<const uint32_t*>(S + (long long)(sya + r) * sp + sxa + c);  // may run past Ls.w inside the aligned row
+      }
+    } else {
+#pragma unroll
+      for (int it = 0; it < 6; it++) {
+        const int      r = min((tid >> 6) + 4 * it, nrow - 1);
+        const uint8_t* p = S + (long long)(sya + r) * sp + sxa + c;
+        v[it]            = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[it] |= (uint32_t)p[min(k, Ls.w - 1 - sxa - c)] << (8 * k);
+      }
     }
-    *reinterpret_cast<uint32_t*>(&src[r][c]) = v;
+#pragma unroll
+    for (int it = 0; it < 6; it++) {
+      const int r = (tid >> 6) + 4 * it;
+      if (colIn && r < nrow) *reinterpret_cast<uint32_t*>(&src[r][c]) = v[it];
+    }
   }
   __syncthreads();
   const int dx = dx0 + (tid & 31) * 4;
   if (dx >= L.w) return;
-  int  sx[4], a0[4], a1[4];
+  // The four taps of a pixel sit at LDS offsets {0, 1, row, row + 1} from ONE address.  Where cv::resize clamps the second
+  // column / row to the last source column / row its weight is 0 (fx = 0 / fy = 0 there), so the unclamped neighbour --
+  // a stale byte of the LDS row, or the spare LDS row -- is read and multiplied by 0.
+  int sx[4], a0[4], a1[4];
 #pragma unroll
   for (int k = 0; k < 4; k++) {
     const int2 xt = b.xtab[L.xtabOff + min(dx + k, L.w - 1)];
@@ -126,15 +142,20 @@ __global__ __launch_bounds__(256) void k_resize_level(Bufs b, FrameGeom g, int l
     const int dy = dy0 + (tid >> 5) * 2 + rr;
     if (dy >= L.h) break;
     const int2 yt = b.ytab[L.ytabOff + dy];
-    const int  r0 = min(max(yt.x, 0), Ls.h - 1) - sya, r1 = min(max(yt.x + 1, 0), Ls.h - 1) - sya;
+    const int  r0 = min(max(yt.x, 0), Ls.h - 1) - sya;
     const int  b0 = (short)(yt.y & 0xffff), b1 = yt.y >> 16;
     uint32_t   out = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-      const int x1 = min(sx[k] + 1, Ls.w - 1 - sxa);  // second tap clamps at the last source column (weight 0 there)
-      const int h0 = src[r0][sx[k]] * a0[k] + src[r0][x1] * a1[k];
-      const int h1 = src[r1][sx[k]] * a0[k] + src[r1][x1] * a1[k];
-      const int v  = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+      // Byte reads on purpose: left alone the compiler fuses columns c and c + 1 into one ds_read_u16 at an odd address
+      // half of the time, and unaligned LDS reads run at a third of the speed here (measured: the level chain went from
+      // 0.24 to 0.65 ms).  The row below is the same address + one LDS row (immediate offset).
+      const int c = sx[k];
+      int       c1 = c + 1;
+      asm volatile("" : "+v"(c1));
+      const int h0 = src[r0][c] * a0[k] + src[r0][c1] * a1[k];
+      const int h1 = src[r0 + 1][c] * a0[k] + src[r0 + 1][c1] * a1[k];
+      const int      v  = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
       out |= (uint32_t)(v & 0xff) << (8 * k);
     }
     // pitch is a multiple of 64: lanes past L.w write into the row's padding
