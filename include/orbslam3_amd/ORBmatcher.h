@@ -84,6 +84,32 @@ class ORBmatcher {
     return n;
   }
 
+  // Array core of SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, th, bMono) (src/ORBmatcher.cc:1684-1908,
+  // Nleft == -1).  The caller keeps the loop head (:1706-1729): lastValid[i] = LastFrame.mvpMapPoints[i] && !mvbOutlier[i] &&
+  // invzc >= 0 && uv inside the image bounds; lastUV / lastInvZ = projection and 1/z; lastDesc row i = pMP->GetDescriptor();
+  // lastKeys = LastFrame.mvKeysUn (octave, angle).  curOccupied[i2] = CurrentFrame.mvpMapPoints[i2] with Observations() > 0.
+  // curOfLast[i] = the CurrentFrame feature that receives LastFrame.mvpMapPoints[i] (-1 = none).  direction: 0 neither,
+  // 1 bForward, 2 bBackward (:1701-1702).  INTEGRATION.md shows the forwarding body.
+  int SearchByProjectionArrays(const orbx_cv::Mat& lastDesc, const std::vector<orbx_cv::Point2f>& lastUV, const std::vector<float>& lastInvZ,
+                               const std::vector<orbx_cv::KeyPoint>& lastKeys, const std::vector<unsigned char>& lastValid,
+                               const orbx_cv::Mat& curDesc, const std::vector<orbx_cv::KeyPoint>& curKeysUn, const std::vector<float>* curURight,
+                               const std::vector<unsigned char>* curOccupied, const std::vector<float>& scaleFactors, float th, int direction,
+                               float mbf, const float bounds[4], std::vector<int>& curOfLast) {
+    const int n1 = (int)lastKeys.size(), n2 = (int)curKeysUn.size();
+    curOfLast.assign(n1, -1);
+    std::vector<uint8_t> d1 = pack(lastDesc), d2 = pack(curDesc);
+    std::vector<int>     oct(n1);
+    std::vector<float>   ang(n1);
+    for (int i = 0; i < n1; i++) oct[i] = lastKeys[i].octave, ang[i] = lastKeys[i].angle;
+    int n = orbm_search_by_projection(h_, d1.data(), reinterpret_cast<const float*>(lastUV.data()), lastInvZ.empty() ? nullptr : lastInvZ.data(),
+                                      oct.data(), ang.data(), lastValid.empty() ? nullptr : lastValid.data(), n1, d2.data(),
+                                      reinterpret_cast<const orbx_keypoint_t*>(curKeysUn.data()), curURight ? curURight->data() : nullptr,
+                                      curOccupied ? curOccupied->data() : nullptr, n2, scaleFactors.data(), (int)scaleFactors.size(), th, direction,
+                                      mbf, bounds[0], bounds[1], bounds[2], bounds[3], TH_HIGH, mbCheckOrientation ? 1 : 0, curOfLast.data(), nullptr);
+    if (n <= -2) throw std::runtime_error(std::string("orbm_search_by_projection: ") + orbx_last_error());
+    return n;
+  }
+
   orbm_t* handle() { return h_; }
 
  protected:

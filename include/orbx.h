@@ -158,6 +158,22 @@ int orbm_match_window(orbm_t* h, const uint8_t* d1, const orbx_keypoint_t* kp1, 
                       const orbx_keypoint_t* kp2, int n2, float* prev_matched, float min_x, float max_x, float min_y,
                       float max_y, int window, int th, float ratio, int check_ori, int* matches12);
 
+/* ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, th, bMono) (src/ORBmatcher.cc:1684-1908,
+ * CurrentFrame.Nleft == -1) with Frame::GetFeaturesInArea over the 64 x 48 grid (src/Frame.cc:788-865).
+ * The caller does the geometry of the loop head (:1706-1729): last_valid[i] = MapPoint present, not an outlier, in front of
+ * the camera and projecting inside the image bounds; last_uv[i] = projection, last_invz[i] = 1/z (needed only with
+ * cur_u_right), last_octave / last_angle = the last frame's keypoint, last_desc = MapPoint::GetDescriptor().
+ * cur_kp = undistorted keypoints; cur_u_right = mvuRight or NULL (monocular); cur_occupied[i2] = the feature already holds
+ * a MapPoint with observations (NULL = none).  dir: 0 neither, 1 bForward, 2 bBackward (:1701-1702); th_dist = TH_HIGH.
+ * A matched feature is closed to later points (all tracked points are taken to have observations; the zero-observation
+ * temporal points of stereo/RGB-D odometry stay with the caller).  Outputs cur_of_last[n1], last_of_cur[n2] (may be NULL);
+ * returns nmatches.  Host pointers, synchronous. */
+int orbm_search_by_projection(orbm_t* h, const uint8_t* last_desc, const float* last_uv, const float* last_invz, const int* last_octave,
+                              const float* last_angle, const uint8_t* last_valid, int n1, const uint8_t* cur_desc,
+                              const orbx_keypoint_t* cur_kp, const float* cur_u_right, const uint8_t* cur_occupied, int n2,
+                              const float* scale_factors, int nlevels, float th, int dir, float mbf, float min_x, float max_x,
+                              float min_y, float max_y, int th_dist, int check_ori, int* cur_of_last, int* last_of_cur);
+
 /* ---------------------------------------------------------------------------------------------------------
  * ORBVocabulary::transform -- DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB> as
  * Frame::ComputeBoW uses it (src/Frame.cc:879-884), for the configuration of ORBvoc.txt (scoring L1_NORM, weighting

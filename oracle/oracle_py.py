@@ -278,6 +278,27 @@ def stereo_matches(ex_left, ex_right, kl, dl, kr, dr, mb, mbf):
     return n, u, d
 
 
+def search_by_projection(last_desc, last_uv, last_invz, last_octave, last_angle, last_valid, cur_desc, cur_kp, cur_u_right, cur_occupied,
+                         scale_factors, th, direction, mbf, bounds, th_dist=100, check_ori=True):
+    """ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) at array level (see orb_oracle.h)."""
+    last_desc = np.ascontiguousarray(last_desc, np.uint8)
+    cur_desc = np.ascontiguousarray(cur_desc, np.uint8)
+    cur_kp = np.ascontiguousarray(cur_kp, KP_DTYPE)
+    n1, n2 = len(last_desc), len(cur_desc)
+    uv = np.ascontiguousarray(last_uv, np.float32).reshape(-1, 2)
+    iz = _opt(last_invz, np.float32)
+    oc = np.ascontiguousarray(last_octave, np.int32)
+    an = np.ascontiguousarray(last_angle, np.float32)
+    lv, ur, occ = _opt(last_valid, np.uint8), _opt(cur_u_right, np.float32), _opt(cur_occupied, np.uint8)
+    sf = np.ascontiguousarray(scale_factors, np.float32)
+    col, loc = np.zeros(n1, np.int32), np.zeros(n2, np.int32)
+    L = lib()
+    L.orao_search_by_projection.argtypes = [C.c_void_p] * 6 + [C.c_int] + [C.c_void_p] * 4 + [C.c_int, C.c_void_p, C.c_float, C.c_int] + [C.c_float] * 5 + [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    n = L.orao_search_by_projection(_p(last_desc), _p(uv), _p(iz), _p(oc), _p(an), _p(lv), n1, _p(cur_desc), _p(cur_kp), _p(ur), _p(occ), n2, _p(sf),
+                                    float(th), int(direction), float(mbf), *[float(b) for b in bounds], int(th_dist), int(check_ori), _p(col), _p(loc))
+    return n, col, loc
+
+
 class OracleVocabulary:
     """ORBVocabulary (DBoW2 TemplatedVocabulary, TF_IDF / L1_NORM) restated on the CPU: transform()."""
 

@@ -1173,6 +1173,109 @@ int orao_match_window(const uint8_t* d1, const orao_keypoint_t* kp1, int n1, con
 }
 
 
+// SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, th, bMono) (src/ORBmatcher.cc:1684-1908), Nleft == -1
+int orao_search_by_projection(const uint8_t* last_desc, const float* last_uv, const float* last_invz, const int* last_octave,
+                              const float* last_angle, const uint8_t* last_valid, int n1, const uint8_t* cur_desc,
+                              const orao_keypoint_t* cur_kp, const float* cur_u_right, const uint8_t* cur_occupied, int n2,
+                              const float* mvScaleFactors, float th, int dir, float mbf, float mnMinX, float mnMaxX, float mnMinY,
+                              float mnMaxY, int th_dist, int check_ori, int* cur_of_last, int* last_of_cur) {
+  const int   GRID_COLS = 64, GRID_ROWS = 48;
+  const float gwInv = static_cast<float>(GRID_COLS) / (mnMaxX - mnMinX);
+  const float ghInv = static_cast<float>(GRID_ROWS) / (mnMaxY - mnMinY);
+  std::vector<std::vector<int>> grid((size_t)GRID_COLS * GRID_ROWS);  // AssignFeaturesToGrid / PosInGrid (src/Frame.cc:524-553, 867-877)
+  for (int i = 0; i < n2; i++) {
+    int posX = (int)std::round((cur_kp[i].x - mnMinX) * gwInv);
+    int posY = (int)std::round((cur_kp[i].y - mnMinY) * ghInv);
+    if (posX < 0 || posX >= GRID_COLS || posY < 0 || posY >= GRID_ROWS) continue;
+    grid[(size_t)posX * GRID_ROWS + posY].push_back(i);
+  }
+  std::vector<int> mvpMapPoints(n2, -1);  // CurrentFrame.mvpMapPoints: index of the last-frame point, -1 = none / no observations
+  std::vector<int> curOfLast(n1, -1);
+  std::vector<int> rotHist[HISTO_LENGTH];
+  int              nmatches = 0;
+  const bool       bForward = dir == 1, bBackward = dir == 2;
+  std::vector<int> vIndices2;
+  for (int i = 0; i < n1; i++) {
+    if (last_valid && !last_valid[i]) continue;  // :1706-1729, decided by the caller
+    const float u = last_uv[2 * i], v = last_uv[2 * i + 1];
+    const float invzc       = last_invz ? last_invz[i] : 0.f;
+    const int   nLastOctave = last_octave[i];
+    const float radius      = th * mvScaleFactors[nLastOctave];  // :1736
+    int         minLevel, maxLevel;
+    if (bForward)
+      minLevel = nLastOctave, maxLevel = -1;  // GetFeaturesInArea(u, v, radius, nLastOctave)
+    else if (bBackward)
+      minLevel = 0, maxLevel = nLastOctave;
+    else
+      minLevel = nLastOctave - 1, maxLevel = nLastOctave + 1;
+    // GetFeaturesInArea (src/Frame.cc:788-865)
+    vIndices2.clear();
+    {
+      const float x = u, y = v, r = radius;
+      const int   nMinCellX = std::max(0, (int)std::floor((x - mnMinX - r) * gwInv));
+      const int   nMaxCellX = std::min(GRID_COLS - 1, (int)std::ceil((x - mnMinX + r) * gwInv));
+      const int   nMinCellY = std::max(0, (int)std::floor((y - mnMinY - r) * ghInv));
+      const int   nMaxCellY = std::min(GRID_ROWS - 1, (int)std::ceil((y - mnMinY + r) * ghInv));
+      if (!(nMinCellX >= GRID_COLS || nMaxCellX < 0 || nMinCellY >= GRID_ROWS || nMaxCellY < 0)) {
+        const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+        for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
+          for (int iy = nMinCellY; iy <= nMaxCellY; iy++) {
+            const std::vector<int>& vCell = grid[(size_t)ix * GRID_ROWS + iy];
+            for (size_t j = 0; j < vCell.size(); j++) {
+              const orao_keypoint_t& kpUn = cur_kp[vCell[j]];
+              if (bCheckLevels) {
+                if (kpUn.octave < minLevel) continue;
+                if (maxLevel >= 0 && kpUn.octave > maxLevel) continue;
+              }
+              const float distx = kpUn.x - x, disty = kpUn.y - y;
+              if (std::fabs(distx) < r && std::fabs(disty) < r) vIndices2.push_back(vCell[j]);
+            }
+          }
+      }
+    }
+    if (vIndices2.empty()) continue;
+    const uint8_t* dMP      = last_desc + (size_t)i * 32;
+    int            bestDist = 256, bestIdx2 = -1;
+    for (int i2 : vIndices2) {
+      if (mvpMapPoints[i2] >= 0 || (cur_occupied && cur_occupied[i2])) continue;  // :1764-1768
+      if (cur_u_right && cur_u_right[i2] > 0) {                                    // :1770-1776
+        const float ur = u - mbf * invzc;
+        const float er = std::fabs(ur - cur_u_right[i2]);
+        if (er > radius) continue;
+      }
+      const int dist = orao_hamming(dMP, cur_desc + (size_t)i2 * 32);
+      if (dist < bestDist) {
+        bestDist = dist;
+        bestIdx2 = i2;
+      }
+    }
+    if (bestDist <= th_dist) {  // TH_HIGH (:1788)
+      mvpMapPoints[bestIdx2] = i;
+      curOfLast[i]           = bestIdx2;
+      nmatches++;
+      if (check_ori) rotHist[rotBin(last_angle[i], cur_kp[bestIdx2].angle)].push_back(bestIdx2);
+    }
+  }
+  if (check_ori) {  // :1889-1905
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    int counts[HISTO_LENGTH];
+    for (int i = 0; i < HISTO_LENGTH; i++) counts[i] = (int)rotHist[i].size();
+    orao_three_maxima(counts, HISTO_LENGTH, &ind1, &ind2, &ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i == ind1 || i == ind2 || i == ind3) continue;
+      for (size_t j = 0; j < rotHist[i].size(); j++) {
+        const int idx2 = rotHist[i][j];
+        if (mvpMapPoints[idx2] >= 0) curOfLast[mvpMapPoints[idx2]] = -1;
+        mvpMapPoints[idx2] = -1;
+        nmatches--;
+      }
+    }
+  }
+  if (cur_of_last) memcpy(cur_of_last, curOfLast.data(), sizeof(int) * n1);
+  if (last_of_cur) memcpy(last_of_cur, mvpMapPoints.data(), sizeof(int) * n2);
+  return nmatches;
+}
+
 // ------------------------------------------------------------------------------------------------
 // N2: DBoW2 TemplatedVocabulary<FORB::TDescriptor, FORB>::transform (TF_IDF weighting, L1_NORM scoring)
 // ------------------------------------------------------------------------------------------------

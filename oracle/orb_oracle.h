@@ -108,6 +108,21 @@ int orao_match_window(const uint8_t* d1, const orao_keypoint_t* kp1, int n1, con
                       const orao_keypoint_t* kp2, int n2, float* prev_matched, float min_x, float max_x, float min_y,
                       float max_y, int window, int th, float ratio, int check_ori, int* matches12);
 
+/* ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, th, bMono) (src/ORBmatcher.cc:1684-1908,
+ * CurrentFrame.Nleft == -1) at array level.  The host side of the reference loop -- MapPoint present, not an outlier,
+ * Tcw * x3Dw, invzc >= 0, camera projection inside [mnMinX, mnMaxX] x [mnMinY, mnMaxY] (:1706-1729) -- is the caller's:
+ * last_valid[i] says whether point i reaches the window search, last_uv / last_invz carry uv and invzc.
+ * dir: 0 = neither, 1 = bForward, 2 = bBackward (:1701-1702).  cur_u_right NULL = monocular (mvuRight < 0 everywhere);
+ * cur_occupied[i2] = (CurrentFrame.mvpMapPoints[i2] && Observations() > 0) before the call (NULL = none).  Every match
+ * blocks its feature for later points, i.e. all tracked MapPoints are assumed to have observations (the zero-observation
+ * temporal points of the stereo/RGB-D odometry are the caller's to handle).
+ * Outputs: cur_of_last[n1] (feature that received last-frame point i, -1), last_of_cur[n2].  Returns nmatches. */
+int orao_search_by_projection(const uint8_t* last_desc, const float* last_uv, const float* last_invz, const int* last_octave,
+                              const float* last_angle, const uint8_t* last_valid, int n1, const uint8_t* cur_desc,
+                              const orao_keypoint_t* cur_kp, const float* cur_u_right, const uint8_t* cur_occupied, int n2,
+                              const float* scale_factors, float th, int dir, float mbf, float min_x, float max_x, float min_y,
+                              float max_y, int th_dist, int check_ori, int* cur_of_last, int* last_of_cur);
+
 /* ---- DBoW2 vocabulary tree: ORBVocabulary::transform (N2) ----
  * TemplatedVocabulary<FORB::TDescriptor, FORB> restated for the configuration ORB-SLAM3 ships (ORBvoc.txt header
  * "10 6 0 0": scoring L1_NORM, weighting TF_IDF).  Node i + 1 of the tree is entry i of the arrays (node 0 = root), in the

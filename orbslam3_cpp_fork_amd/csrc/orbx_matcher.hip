@@ -766,6 +766,194 @@ __global__ __launch_bounds__(64) void k_window_resolve(WindowArgs a) {
   if (lane == 0) *a.nmatches = nmatches;
 }
 
+// ------------------------------------------------------------------------------------------------
+// N3: SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, th, bMono) (src/ORBmatcher.cc:1684-1908, Nleft == -1)
+// Query = a last-frame MapPoint already projected by the caller (uv, 1/z, octave, descriptor); candidates come from
+// Frame::GetFeaturesInArea(u, v, th * scale[octave], level range) over the current frame's 64 x 48 grid; the best
+// descriptor distance wins if <= TH_HIGH (no ratio test), a matched feature is closed to later points, rotation histogram.
+// Top-k lists per query in parallel (k_proj_topk), then one wave walks the queries in order with the claim bitmap in LDS.
+// ------------------------------------------------------------------------------------------------
+struct ProjArgs {
+  const uint8_t *        d1, *d2;
+  const float *          uv, *invz, *angle1;
+  const int*             oct1;
+  const uint8_t*         valid1;
+  const orbx_keypoint_t* kp2;
+  const float*           uRight;    // NULL = monocular
+  const uint8_t*         occupied;  // NULL = none
+  int                    n1, n2, ng;
+  const int*             g_idx;
+  const uint8_t *        g_cx, *g_cy;
+  const float*           sf;
+  float                  th, mbf, minX, minY, gwInv, ghInv;
+  int                    dir, thDist, check_ori;
+  uint32_t*              topk;
+  int*                   nvalid;
+  int *                  m12, *m21, *binOf, *nmatches;
+};
+
+struct ProjQuery {
+  float u, v, r, invz;
+  int   minL, maxL, x0, x1, y0, y1;
+  bool  empty;
+};
+
+__device__ __forceinline__ ProjQuery proj_query(const ProjArgs& a, int i) {
+  ProjQuery q;
+  q.u = a.uv[2 * i], q.v = a.uv[2 * i + 1];
+  q.invz      = a.invz ? a.invz[i] : 0.f;
+  const int o = a.oct1[i];
+  q.r         = a.th * a.sf[o];  // :1736
+  if (a.dir == 1)
+    q.minL = o, q.maxL = -1;  // bForward: GetFeaturesInArea(u, v, radius, nLastOctave)
+  else if (a.dir == 2)
+    q.minL = 0, q.maxL = o;   // bBackward
+  else
+    q.minL = o - 1, q.maxL = o + 1;
+  q.x0    = max(0, (int)floorf((q.u - a.minX - q.r) * a.gwInv));  // src/Frame.cc:802-830
+  q.x1    = min(kGridCols - 1, (int)ceilf((q.u - a.minX + q.r) * a.gwInv));
+  q.y0    = max(0, (int)floorf((q.v - a.minY - q.r) * a.ghInv));
+  q.y1    = min(kGridRows - 1, (int)ceilf((q.v - a.minY + q.r) * a.ghInv));
+  q.empty = (q.x0 >= kGridCols) || (q.x1 < 0) || (q.y0 >= kGridRows) || (q.y1 < 0);
+  return q;
+}
+
+// candidate at grid-scan position pos for query q: the feature index, or -1 (outside the window / level range / stereo
+// band, or holding a MapPoint with observations before the call)
+__device__ __forceinline__ int proj_candidate(const ProjArgs& a, const ProjQuery& q, int pos) {
+  const int cx = a.g_cx[pos], cy = a.g_cy[pos];
+  if (cx < q.x0 || cx > q.x1 || cy < q.y0 || cy > q.y1) return -1;
+  const int i2 = a.g_idx[pos];
+  if (a.occupied && a.occupied[i2]) return -1;  // :1764-1768
+  const orbx_keypoint_t kp = a.kp2[i2];
+  if ((q.minL > 0) || (q.maxL >= 0)) {  // bCheckLevels (src/Frame.cc:832-848)
+    if (kp.octave < q.minL) return -1;
+    if (q.maxL >= 0 && kp.octave > q.maxL) return -1;
+  }
+  const float dx = kp.x - q.u, dy = kp.y - q.v;
+  if (!(fabsf(dx) < q.r && fabsf(dy) < q.r)) return -1;
+  if (a.uRight && a.uRight[i2] > 0) {  // :1770-1776
+    const float ur = q.u - a.mbf * q.invz;
+    const float er = fabsf(ur - a.uRight[i2]);
+    if (er > q.r) return -1;
+  }
+  return i2;
+}
+
+__global__ __launch_bounds__(256) void k_proj_topk(ProjArgs a) {
+  const int i1 = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i1 >= a.n1) return;
+  uint32_t out[kTopK];
+  int      nv = 0;
+#pragma unroll
+  for (int j = 0; j < kTopK; j++) out[j] = kEmpty;
+  if (!a.valid1 || a.valid1[i1]) {
+    const ProjQuery q = proj_query(a, i1);
+    if (!q.empty) {
+      const ProjArgs& ar = a;
+      wave_topk(
+          a.d1 + (size_t)i1 * 32, a.d2, 0, a.ng, [&ar, &q](int pos) { return proj_candidate(ar, q, pos); },
+          [thd = ar.thDist](int, int d) { return d <= thd; }, out, &nv);  // only "bestDist <= TH_HIGH" can match (:1788)
+    }
+  }
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int j = 0; j < kTopK; j++) a.topk[(size_t)i1 * kTopK + j] = out[j];
+    a.nvalid[i1] = nv;
+  }
+}
+
+constexpr int kProjStage = 512;  // K-lists staged in LDS per pass of the resolve wave
+
+__global__ __launch_bounds__(64) void k_proj_resolve(ProjArgs a) {
+  __shared__ uint32_t claimed[kMaxTrainW / 32];
+  __shared__ uint32_t sList[kProjStage][kTopK];
+  __shared__ int      sNv[kProjStage];
+  __shared__ int      hist[kHistoLen];
+  const int           lane = threadIdx.x;
+  for (int i = lane; i < kMaxTrainW / 32; i += 64) claimed[i] = 0;
+  for (int i = lane; i < a.n2; i += 64) a.m21[i] = -1;
+  for (int i = lane; i < a.n1; i += 64) a.m12[i] = -1;
+  for (int i = lane; i < kHistoLen; i += 64) hist[i] = 0;
+  __syncthreads();
+  int nmatches = 0;
+  for (int s0 = 0; s0 < a.n1; s0 += kProjStage) {
+    const int ns = min(kProjStage, a.n1 - s0);
+    for (int t = lane; t < ns * kTopK; t += 64) sList[t / kTopK][t % kTopK] = a.topk[(size_t)s0 * kTopK + t];
+    for (int t = lane; t < ns; t += 64) sNv[t] = a.nvalid[s0 + t];
+    __syncthreads();
+    for (int e = 0; e < ns; e++) {  // strictly in LastFrame order: every step is a handful of LDS reads
+      const int i1 = s0 + e;
+      if (sList[e][0] == kEmpty) continue;  // wave-uniform
+      uint32_t key = kEmpty;
+      bool     fr  = false;
+      if (lane < kTopK) {
+        key = sList[e][lane];
+        if (key != kEmpty) {
+          const int i2 = a.g_idx[key & kPosMask];
+          fr           = !(claimed[i2 >> 5] & (1u << (i2 & 31)));
+        }
+      }
+      const unsigned long long freeMask = __ballot(fr), haveMask = __ballot(key != kEmpty);
+      int                      best2    = -1;
+      if (freeMask) {
+        const int j = __ffsll((long long)freeMask) - 1;  // entries are sorted by (distance, scan position)
+        best2       = a.g_idx[__shfl((int)key, j, 64) & kPosMask];
+      } else if (sNv[e] > __popcll(haveMask)) {
+        // the list ran dry but was truncated: exact rescan of this point's window with the claim filter
+        const ProjQuery q  = proj_query(a, i1);
+        const ProjArgs& ar = a;
+        const uint32_t* cl = claimed;
+        uint32_t        out[kTopK];
+        int             nv;
+        wave_topk(
+            a.d1 + (size_t)i1 * 32, a.d2, 0, a.ng,
+            [&ar, &q, cl](int pos) {
+              const int i2 = proj_candidate(ar, q, pos);
+              return (i2 >= 0 && (cl[i2 >> 5] & (1u << (i2 & 31)))) ? -1 : i2;
+            },
+            [thd = ar.thDist](int, int d) { return d <= thd; }, out, &nv);
+        if (out[0] != kEmpty) best2 = a.g_idx[out[0] & kPosMask];
+      }
+      if (best2 >= 0) {  // wave-uniform
+        if (lane == 0) {
+          claimed[best2 >> 5] |= 1u << (best2 & 31);  // CurrentFrame.mvpMapPoints[bestIdx2] = pMP (:1789)
+          a.m12[i1]    = best2;
+          a.m21[best2] = i1;
+          if (a.check_ori) {
+            const int bin = rot_bin(a.angle1[i1], a.kp2[best2].angle);
+            hist[bin]++;
+            a.binOf[i1] = bin;
+          }
+        }
+        nmatches++;
+        __syncthreads();
+      }
+    }
+    __syncthreads();
+  }
+  if (a.check_ori) {  // :1889-1905
+    int i1m, i2m, i3m;
+    three_maxima(hist, kHistoLen, i1m, i2m, i3m);
+    int removed = 0;
+    for (int q0 = 0; q0 < a.n1; q0 += 64) {
+      const int q   = q0 + lane;
+      bool      off = false;
+      if (q < a.n1 && a.m12[q] >= 0) {
+        const int bin = a.binOf[q];
+        if (bin != i1m && bin != i2m && bin != i3m) {
+          a.m21[a.m12[q]] = -1;
+          a.m12[q]        = -1;
+          off             = true;
+        }
+      }
+      removed += __popcll(__ballot(off));
+    }
+    nmatches -= removed;
+  }
+  if (lane == 0) *a.nmatches = nmatches;
+}
+
 // Exact pruning bound of the top-K pass.  A match needs best <= th (or < th) and best < ratio * second.  Let D* be the
 // smallest integer with (float)th < ratio * (float)D*.  A candidate at distance >= D* can never be the best of an
 // accepted match (D* > th), and as a runner-up it passes the ratio test for EVERY admissible best -- exactly as a
@@ -1120,6 +1308,97 @@ int orbm_match_window(orbm_t* h, const uint8_t* d1, const orbx_keypoint_t* kp1, 
     HIP_TRYM(hipMemcpyAsync(matches12, h->mq.p, (size_t)n1 * 4, hipMemcpyDeviceToHost, s));
     HIP_TRYM(hipMemcpyAsync(prev_matched, h->prev.p, (size_t)n1 * 8, hipMemcpyDeviceToHost, s));
   }
+  HIP_TRYM(hipStreamSynchronize(s));
+  return nm;
+}
+
+// ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, th, bMono) at array level (see include/orbx.h)
+int orbm_search_by_projection(orbm_t* h, const uint8_t* last_desc, const float* last_uv, const float* last_invz, const int* last_octave,
+                              const float* last_angle, const uint8_t* last_valid, int n1, const uint8_t* cur_desc,
+                              const orbx_keypoint_t* cur_kp, const float* cur_u_right, const uint8_t* cur_occupied, int n2,
+                              const float* scale_factors, int nlevels, float th, int dir, float mbf, float min_x, float max_x,
+                              float min_y, float max_y, int th_dist, int check_ori, int* cur_of_last, int* last_of_cur) {
+  if (!h || n1 < 0 || n2 < 0 || !cur_of_last || (n1 > 0 && (!last_desc || !last_uv || !last_octave || !last_angle)) ||
+      (n2 > 0 && (!cur_desc || !cur_kp)) || !scale_factors || nlevels < 1 || nlevels > 64 || dir < 0 || dir > 2 || !(max_x > min_x) ||
+      !(max_y > min_y) || (cur_u_right && n1 > 0 && !last_invz)) {
+    set_err("orbm_search_by_projection: bad arguments");
+    return -2;
+  }
+  if (n2 > kMaxTrainW) {
+    set_err("orbm_search_by_projection: more than 16384 current-frame features");
+    return -2;
+  }
+  for (int i = 0; i < n1; i++)
+    if ((!last_valid || last_valid[i]) && (last_octave[i] < 0 || last_octave[i] >= nlevels)) {
+      set_err("orbm_search_by_projection: octave outside the scale table");
+      return -2;
+    }
+  HIP_TRYM(hipSetDevice(h->device));
+  // Frame::AssignFeaturesToGrid / PosInGrid (src/Frame.cc:524-553, 867-877), host side as in orbm_match_window: the scan order
+  // of GetFeaturesInArea is cells (ix, iy) ascending, insertion (= index) order inside, so one global order serves every window.
+  const float      gwInv = static_cast<float>(kGridCols) / (max_x - min_x);
+  const float      ghInv = static_cast<float>(kGridRows) / (max_y - min_y);
+  std::vector<int> cellCount(kGridCols * kGridRows + 1, 0), cellOf(n2, -1);
+  for (int i = 0; i < n2; i++) {
+    const int posX = (int)std::round((cur_kp[i].x - min_x) * gwInv);
+    const int posY = (int)std::round((cur_kp[i].y - min_y) * ghInv);
+    if (posX < 0 || posX >= kGridCols || posY < 0 || posY >= kGridRows) continue;
+    cellOf[i] = posX * kGridRows + posY;
+    cellCount[cellOf[i] + 1]++;
+  }
+  for (int c = 0; c < kGridCols * kGridRows; c++) cellCount[c + 1] += cellCount[c];
+  const int            ng = cellCount[kGridCols * kGridRows];
+  std::vector<int>     gidx(ng + 1);
+  std::vector<uint8_t> gcx(ng + 1), gcy(ng + 1);
+  {
+    std::vector<int> fill(cellCount.begin(), cellCount.end() - 1);
+    for (int i = 0; i < n2; i++)
+      if (cellOf[i] >= 0) {
+        const int p = fill[cellOf[i]]++;
+        gidx[p]     = i;
+        gcx[p]      = (uint8_t)(cellOf[i] / kGridRows);
+        gcy[p]      = (uint8_t)(cellOf[i] % kGridRows);
+      }
+  }
+  hipStream_t s = h->stream;
+  if (h->dq.ensure((size_t)n1 * 32 + 32) || h->dt.ensure((size_t)n2 * 32 + 32) || h->kp2.ensure(n2 + 1) || h->gidx.ensure(ng + 1) ||
+      h->gcx.ensure(ng + 1) || h->gcy.ensure(ng + 1) || h->prev.ensure((size_t)2 * n1 + 2) || h->qa.ensure((size_t)2 * n1 + 2) ||
+      h->ta.ensure((size_t)n2 + 66) || h->qoff.ensure(n1 + 1) || h->dqv.ensure(n1 + 1) || h->dtv.ensure(n2 + 1) ||
+      h->topk.ensure((size_t)(n1 + 1) * kTopK) || h->nvalid.ensure(n1 + 1) || h->binOf.ensure(n1 + 1) || h->mq.ensure(n1 + 1) ||
+      h->mt.ensure(n2 + 1) || h->nm.ensure(1))
+    return -3;
+  auto up = [&](void* d, const void* src, size_t bytes) -> hipError_t {
+    return bytes ? hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, s) : hipSuccess;
+  };
+  // device layout: prev = uv; qa = [angle | invz]; ta = [scale factors (64) | uRight]; qoff = octaves; dqv / dtv = valid / occupied
+  HIP_TRYM(up(h->dq.p, last_desc, (size_t)n1 * 32));
+  HIP_TRYM(up(h->dt.p, cur_desc, (size_t)n2 * 32));
+  HIP_TRYM(up(h->kp2.p, cur_kp, (size_t)n2 * sizeof(orbx_keypoint_t)));
+  HIP_TRYM(up(h->gidx.p, gidx.data(), (size_t)ng * 4));
+  HIP_TRYM(up(h->gcx.p, gcx.data(), ng));
+  HIP_TRYM(up(h->gcy.p, gcy.data(), ng));
+  HIP_TRYM(up(h->prev.p, last_uv, (size_t)n1 * 8));
+  HIP_TRYM(up(h->qa.p, last_angle, (size_t)n1 * 4));
+  if (last_invz) HIP_TRYM(up(h->qa.p + n1, last_invz, (size_t)n1 * 4));
+  HIP_TRYM(up(h->ta.p, scale_factors, (size_t)nlevels * 4));
+  if (cur_u_right) HIP_TRYM(up(h->ta.p + 64, cur_u_right, (size_t)n2 * 4));
+  HIP_TRYM(up(h->qoff.p, last_octave, (size_t)n1 * 4));
+  if (last_valid) HIP_TRYM(up(h->dqv.p, last_valid, n1));
+  if (cur_occupied) HIP_TRYM(up(h->dtv.p, cur_occupied, n2));
+  ProjArgs a;
+  memset(&a, 0, sizeof(a));
+  a.d1 = h->dq.p, a.d2 = h->dt.p, a.uv = h->prev.p, a.invz = last_invz ? h->qa.p + n1 : nullptr, a.angle1 = h->qa.p, a.oct1 = h->qoff.p;
+  a.valid1 = last_valid ? h->dqv.p : nullptr, a.kp2 = h->kp2.p, a.uRight = cur_u_right ? h->ta.p + 64 : nullptr;
+  a.occupied = cur_occupied ? h->dtv.p : nullptr, a.n1 = n1, a.n2 = n2, a.ng = ng, a.g_idx = h->gidx.p, a.g_cx = h->gcx.p, a.g_cy = h->gcy.p;
+  a.sf = h->ta.p, a.th = th, a.mbf = mbf, a.minX = min_x, a.minY = min_y, a.gwInv = gwInv, a.ghInv = ghInv, a.dir = dir, a.thDist = th_dist;
+  a.check_ori = check_ori, a.topk = h->topk.p, a.nvalid = h->nvalid.p, a.m12 = h->mq.p, a.m21 = h->mt.p, a.binOf = h->binOf.p, a.nmatches = h->nm.p;
+  if (n1 > 0) hipLaunchKernelGGL(k_proj_topk, dim3((n1 + 3) / 4), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_proj_resolve, dim3(1), dim3(64), 0, s, a);
+  HIP_TRYM(hipGetLastError());
+  int nm = 0;
+  HIP_TRYM(hipMemcpyAsync(&nm, h->nm.p, 4, hipMemcpyDeviceToHost, s));
+  if (n1) HIP_TRYM(hipMemcpyAsync(cur_of_last, h->mq.p, (size_t)n1 * 4, hipMemcpyDeviceToHost, s));
+  if (n2 && last_of_cur) HIP_TRYM(hipMemcpyAsync(last_of_cur, h->mt.p, (size_t)n2 * 4, hipMemcpyDeviceToHost, s));
   HIP_TRYM(hipStreamSynchronize(s));
   return nm;
 }

@@ -118,6 +118,33 @@ class ORBmatcher:
         )
         return n, m12, pm
 
+    def SearchByProjection(self, last_desc, last_uv, last_octave, last_angle, cur_kps, cur_desc, scale_factors, th, bounds, last_valid=None,
+                           last_invz=None, cur_u_right=None, cur_occupied=None, direction=0, mbf=0.0, check_ori=None):
+        """SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, th, bMono) (src/ORBmatcher.cc:1684-1908, Nleft == -1) on
+        arrays: last_* describe the last frame's MapPoints already projected into the current frame by the caller, cur_kps are the
+        current frame's undistorted keypoints (KP_DTYPE), bounds = (mnMinX, mnMaxX, mnMinY, mnMaxY), direction 0 / 1 (bForward) /
+        2 (bBackward).  Returns (nmatches, cur_of_last[n1], last_of_cur[n2])."""
+        d1 = np.ascontiguousarray(last_desc, np.uint8).reshape(-1, 32)
+        d2 = np.ascontiguousarray(cur_desc, np.uint8).reshape(-1, 32)
+        kp2 = np.ascontiguousarray(cur_kps, KP_DTYPE)
+        n1, n2 = len(d1), len(d2)
+        uv = np.ascontiguousarray(last_uv, np.float32).reshape(-1, 2)
+        oc = np.ascontiguousarray(last_octave, np.int32)
+        an = np.ascontiguousarray(last_angle, np.float32)
+        sf = np.ascontiguousarray(scale_factors, np.float32)
+        opt = lambda a, dt: None if a is None else np.ascontiguousarray(a, dt)
+        lv, iz, ur, occ = opt(last_valid, np.uint8), opt(last_invz, np.float32), opt(cur_u_right, np.float32), opt(cur_occupied, np.uint8)
+        col, loc = np.zeros(n1, np.int32), np.zeros(n2, np.int32)
+        n = check(
+            _lib.lib().orbm_search_by_projection(
+                self._h, ptr(d1), ptr(uv), ptr(iz), ptr(oc), ptr(an), ptr(lv), n1, ptr(d2), ptr(kp2), ptr(ur), ptr(occ), n2, ptr(sf), len(sf), float(th),
+                int(direction), float(mbf), float(bounds[0]), float(bounds[1]), float(bounds[2]), float(bounds[3]), self.TH_HIGH,
+                int(self.mbCheckOrientation if check_ori is None else check_ori), ptr(col), ptr(loc),
+            ),
+            "orbm_search_by_projection",
+        )
+        return n, col, loc
+
     def match_bruteforce_device(self, d_q, d_q_kp, d_nq, cap_q, d_t, d_t_kp, d_nt, cap_t, d_match, d_nmatches, th=None, strict_lt=False, stream=None):
         """Device-resident brute-force SearchByBoW (one group): enqueue only."""
         return check(

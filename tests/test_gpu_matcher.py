@@ -112,3 +112,49 @@ def test_search_for_initialization(oracle, synth):
     mm.TH_LOW = 80
     n1, m1, p1 = mm.SearchForInitialization(k1, d1, k2, d2b, prev, bounds, 100)
     assert n0 == n1 and (m0 == m1).all() and (p0 == p1).all()
+
+
+@pytest.mark.parametrize("direction,stereo,th", [(0, False, 15.0), (1, True, 7.0), (2, True, 15.0), (0, True, 30.0)])
+def test_search_by_projection(oracle, direction, stereo, th):
+    """N3: SearchByProjection(CurrentFrame, LastFrame, th, bMono) -- window search over the frame grid, greedy claims, TH_HIGH,
+    rotation histogram -- on two consecutive frames of the synthetic stream, the 'projection' being the last position plus the
+    stream's shift plus noise."""
+    from orbslam3_cpp_fork_amd import synth as S
+    from orbslam3_cpp_fork_amd.matcher import ORBmatcher
+
+    frames = S.make_stream(480, 640, 2, camera_idx=4)
+    oex = oracle.OracleExtractor(1000, 1.2, 8, 20, 7)
+    _, kA, dA = oex(frames[0], (0, 1000))
+    _, kB, dB = oex(frames[1], (0, 1000))
+    sf = oex.scale_tables()[0]
+    rng = np.random.default_rng(17 + direction)
+    n1, n2 = len(kA), len(kB)
+    # estimate the stream shift from brute-force matches, then perturb it per point
+    _, mq, _ = oracle.match_groups(dA, dB, kA["angle"], kB["angle"], 50, 0.7, False, True)
+    ok = mq >= 0
+    shift = np.median(np.stack([kB["x"][mq[ok]] - kA["x"][ok], kB["y"][mq[ok]] - kA["y"][ok]], 1), axis=0)
+    uv = np.stack([kA["x"], kA["y"]], 1) + shift + rng.normal(0, 3.0, (n1, 2))
+    uv = uv.astype(np.float32)
+    valid = ((uv[:, 0] >= 0) & (uv[:, 0] <= 640) & (uv[:, 1] >= 0) & (uv[:, 1] <= 480) & (rng.random(n1) < 0.9)).astype(np.uint8)
+    invz = rng.uniform(0.02, 1.0, n1).astype(np.float32)
+    occ = (rng.random(n2) < 0.1).astype(np.uint8)
+    ur = None
+    mbf = 0.0
+    if stereo:
+        mbf = 40.0
+        ur = np.where(rng.random(n2) < 0.7, kB["x"] - rng.uniform(0.0, 40.0, n2), -1.0).astype(np.float32)
+    bounds = (0.0, 640.0, 0.0, 480.0)
+    for check_ori in (True, False):
+        ref = oracle.search_by_projection(dA, uv, invz, kA["octave"], kA["angle"], valid, dB, kB, ur, occ, sf, th, direction, mbf, bounds, 100, check_ori)
+        m = ORBmatcher(0.9, check_ori)
+        got = m.SearchByProjection(dA, uv, kA["octave"], kA["angle"], kB, dB, sf, th, bounds, last_valid=valid, last_invz=invz, cur_u_right=ur,
+                                   cur_occupied=occ, direction=direction, mbf=mbf)
+        assert got[0] == ref[0] and got[1].tolist() == ref[1].tolist() and got[2].tolist() == ref[2].tolist()
+        assert ref[0] > (50 if not stereo else 5)
+    # duplicated descriptors force ties and exhausted lists: every current feature is a copy of one of 12 descriptors
+    dB2 = dB[rng.integers(0, 12, n2)]
+    dA2 = dB2[rng.integers(0, n2, n1)]
+    ref = oracle.search_by_projection(dA2, uv, invz, kA["octave"], kA["angle"], valid, dB2, kB, ur, occ, sf, 60.0, 0, mbf, bounds, 100, True)
+    got = ORBmatcher(0.9, True).SearchByProjection(dA2, uv, kA["octave"], kA["angle"], kB, dB2, sf, 60.0, bounds, last_valid=valid, last_invz=invz,
+                                                   cur_u_right=ur, cur_occupied=occ, direction=0, mbf=mbf)
+    assert got[0] == ref[0] and got[1].tolist() == ref[1].tolist() and got[2].tolist() == ref[2].tolist()

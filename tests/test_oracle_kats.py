@@ -380,3 +380,37 @@ def test_vocabulary_transform_kat(oracle):
     v2 = oracle.OracleVocabulary(1, 1, [0], [1], np.zeros((1, 32), np.uint8), [0.1])
     wi, wv, *_ = v2.transform(np.zeros((3, 32), np.uint8), levelsup=0)
     assert wv.tolist() == [(0.1 + 0.1 + 0.1) / abs(0.1 + 0.1 + 0.1)]
+
+
+def test_search_by_projection_kat(oracle):
+    """SearchByProjection(CurrentFrame, LastFrame) (src/ORBmatcher.cc:1684-1908) on a hand-made scene: greedy claims in LastFrame
+    order, level window nLastOctave +- 1, |dx|, |dy| < th * scale, TH_HIGH, the stereo band on mvuRight, occupied features."""
+    KP = oracle.KP_DTYPE
+    cur = np.zeros(4, KP)
+    cur["x"], cur["y"], cur["octave"], cur["angle"] = [100, 104, 300, 100], [100, 100, 200, 100], [0, 0, 3, 5], [10, 10, 10, 10]
+    dcur = np.zeros((4, 32), np.uint8)
+    dcur[1, 0] = 0x01  # feature 1 is one bit away from the query descriptor, feature 0 identical
+    dcur[3, :] = 0xFF
+    sf = np.array([1.0, 1.2, 1.44, 1.728, 2.0736], np.float32)
+    last_desc = np.zeros((3, 32), np.uint8)
+    uv = np.array([[101, 100], [101, 100], [300, 200]], np.float32)
+    octv, ang = np.array([0, 1, 0], np.int32), np.array([10, 10, 10], np.float32)
+    bounds = (0.0, 640.0, 0.0, 480.0)
+    n, col, loc = oracle.search_by_projection(last_desc, uv, None, octv, ang, None, dcur, cur, None, None, sf, 7.0, 0, 0.0, bounds, 100, False)
+    # point 0 takes feature 0 (distance 0); point 1 (octave 1: levels 0..2) finds it taken and takes feature 1 (distance 1);
+    # point 2 sits on feature 2 but that one is on level 3, outside 0 +- 1
+    assert n == 2 and col.tolist() == [0, 1, -1] and loc.tolist() == [0, 1, -1, -1]
+    # occupied feature 0: point 0 falls back to feature 1, point 1 gets nothing
+    n, col, _ = oracle.search_by_projection(last_desc, uv, None, octv, ang, None, dcur, cur, None, np.array([1, 0, 0, 0], np.uint8), sf, 7.0, 0, 0.0, bounds, 100, False)
+    assert n == 1 and col.tolist() == [1, -1, -1]
+    # bForward: levels >= nLastOctave only -> point 1 (octave 1) sees no level-0 feature; for point 2 (octave 0) the call is
+    # GetFeaturesInArea(u, v, r, 0, -1): bCheckLevels is false, so the level-3 feature under it now qualifies
+    n, col, _ = oracle.search_by_projection(last_desc, uv, None, octv, ang, None, dcur, cur, None, None, sf, 7.0, 1, 0.0, bounds, 100, False)
+    assert n == 2 and col.tolist() == [0, -1, 2]
+    # stereo band: ur = u - mbf * invz = 101 - 40 * 0.5 = 81; feature 0 has uRight 95 (|81 - 95| > 7) -> skipped, feature 1 has none
+    ur = np.array([95, -1, -1, -1], np.float32)
+    n, col, _ = oracle.search_by_projection(last_desc, uv, np.full(3, 0.5, np.float32), octv, ang, None, dcur, cur, ur, None, sf, 7.0, 0, 40.0, bounds, 100, False)
+    assert n == 1 and col.tolist() == [1, -1, -1]
+    # window is open: |dx| < r.  Feature 1 at x = 104 is 3 px from u = 101: r = 3 excludes it (and keeps feature 0 at 1 px)
+    n, col, _ = oracle.search_by_projection(last_desc[:1], uv[:1], None, octv[:1], ang[:1], None, dcur[1:2], cur[1:2], None, None, sf, 3.0, 0, 0.0, bounds, 100, False)
+    assert n == 0
