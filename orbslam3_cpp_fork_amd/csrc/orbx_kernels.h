@@ -1234,18 +1234,38 @@ __global__ __launch_bounds__(256) void k_stereo_cut(StereoArgs a, int* kept) {
     if (tid == 0) *kept = 0;
     return;
   }
-  // std::sort of (dist, iL) pairs, element n/2: its rank = #(smaller dist) + #(equal dist, smaller iL)
+  // std::sort of (dist, iL) pairs, element n/2: only its DISTANCE is used, i.e. the (k + 1)-th smallest distance = the
+  // smallest d with #(dist <= d) >= k + 1.  Found by bisection on d; each step counts with all threads (each keeps its
+  // distances in registers, loaded once).
   const int k = n / 2;
-  for (int i = tid; i < a.nl; i += 256) {
-    const int di = a.sad[i];
-    if (di < 0) continue;
-    int rank = 0;
-    for (int j = 0; j < a.nl; j++) {
-      const int dj = a.sad[j];
-      rank += (dj >= 0 && (dj < di || (dj == di && j < i))) ? 1 : 0;
-    }
-    if (rank == k) sMedian = di;
+  constexpr int kPer = 32;  // 256 x 32 = 8192 left keypoints held in registers; beyond that the tail is re-read
+  int           mine[kPer];
+#pragma unroll
+  for (int r = 0; r < kPer; r++) {
+    const int i = tid + 256 * r;
+    mine[r]     = i < a.nl ? a.sad[i] : -1;
   }
+  int lo = 0, hi = 11 * 11 * 255;  // SAD of an 11 x 11 u8 window
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    int       c   = 0;
+#pragma unroll
+    for (int r = 0; r < kPer; r++) c += (mine[r] >= 0 && mine[r] <= mid) ? 1 : 0;
+    for (int i = tid + 256 * kPer; i < a.nl; i += 256) {
+      const int d = a.sad[i];
+      c += (d >= 0 && d <= mid) ? 1 : 0;
+    }
+    __syncthreads();
+    if (tid == 0) sCount = 0;
+    __syncthreads();
+    if (c) atomicAdd(&sCount, c);
+    __syncthreads();
+    if (sCount >= k + 1)
+      hi = mid;
+    else
+      lo = mid + 1;
+  }
+  if (tid == 0) sMedian = lo;
   __syncthreads();
   const float median = (float)sMedian;
   const float thDist = 1.5f * 1.4f * median;

@@ -863,75 +863,105 @@ __global__ __launch_bounds__(256) void k_proj_topk(ProjArgs a) {
   }
 }
 
-constexpr int kProjStage = 512;  // K-lists staged in LDS per pass of the resolve wave
+// The reference walks the points one by one; a point's choice only depends on which features EARLIER points took.  The wave
+// takes 64 consecutive points (lane = point, its 8-deep list in registers) and runs rounds: every undecided lane proposes its
+// first feature not yet taken; the proposals of the lanes before the first CONFLICT (a lane proposing what an earlier lane of
+// this round proposes) are exactly what the sequential walk would do -- a committed proposal can only remove features that the
+// later lanes' lists had already skipped or that they were not proposing -- so that prefix commits at once and the rest
+// retries.  A lane whose list ran dry although more candidates exist stops the prefix and is rescanned exactly.
+constexpr int kProjTab = 1024;  // proposal table (earliest proposing lane per hashed feature)
 
 __global__ __launch_bounds__(64) void k_proj_resolve(ProjArgs a) {
   __shared__ uint32_t claimed[kMaxTrainW / 32];
-  __shared__ uint32_t sList[kProjStage][kTopK];
-  __shared__ int      sNv[kProjStage];
+  __shared__ uint32_t minLane[kProjTab];
   __shared__ int      hist[kHistoLen];
   const int           lane = threadIdx.x;
   for (int i = lane; i < kMaxTrainW / 32; i += 64) claimed[i] = 0;
+  for (int i = lane; i < kProjTab; i += 64) minLane[i] = 0xffu;
   for (int i = lane; i < a.n2; i += 64) a.m21[i] = -1;
   for (int i = lane; i < a.n1; i += 64) a.m12[i] = -1;
   for (int i = lane; i < kHistoLen; i += 64) hist[i] = 0;
   __syncthreads();
   int nmatches = 0;
-  for (int s0 = 0; s0 < a.n1; s0 += kProjStage) {
-    const int ns = min(kProjStage, a.n1 - s0);
-    for (int t = lane; t < ns * kTopK; t += 64) sList[t / kTopK][t % kTopK] = a.topk[(size_t)s0 * kTopK + t];
-    for (int t = lane; t < ns; t += 64) sNv[t] = a.nvalid[s0 + t];
-    __syncthreads();
-    for (int e = 0; e < ns; e++) {  // strictly in LastFrame order: every step is a handful of LDS reads
-      const int i1 = s0 + e;
-      if (sList[e][0] == kEmpty) continue;  // wave-uniform
-      uint32_t key = kEmpty;
-      bool     fr  = false;
-      if (lane < kTopK) {
-        key = sList[e][lane];
-        if (key != kEmpty) {
-          const int i2 = a.g_idx[key & kPosMask];
-          fr           = !(claimed[i2 >> 5] & (1u << (i2 & 31)));
-        }
+  for (int c0 = 0; c0 < a.n1; c0 += 64) {
+    const int i1 = c0 + lane;
+    uint32_t  row[kTopK];  // feature index per list entry (kEmpty = none); the list is sorted by (distance, scan position)
+    int       len = 0, nv = 0;
+#pragma unroll
+    for (int j = 0; j < kTopK; j++) {
+      row[j] = kEmpty;
+      if (i1 < a.n1) {
+        const uint32_t key = a.topk[(size_t)i1 * kTopK + j];
+        if (key != kEmpty) row[j] = (uint32_t)a.g_idx[key & kPosMask], len = j + 1;
       }
-      const unsigned long long freeMask = __ballot(fr), haveMask = __ballot(key != kEmpty);
-      int                      best2    = -1;
-      if (freeMask) {
-        const int j = __ffsll((long long)freeMask) - 1;  // entries are sorted by (distance, scan position)
-        best2       = a.g_idx[__shfl((int)key, j, 64) & kPosMask];
-      } else if (sNv[e] > __popcll(haveMask)) {
-        // the list ran dry but was truncated: exact rescan of this point's window with the claim filter
-        const ProjQuery q  = proj_query(a, i1);
+    }
+    if (i1 < a.n1) nv = a.nvalid[i1];
+    const bool         truncated = nv > len;
+    int                mine      = -1;
+    unsigned long long pending   = __ballot(len > 0);
+    while (pending) {
+      const bool act = (pending >> lane) & 1ull;
+      int        prop = -1;
+      bool       dry  = false;  // list exhausted
+      if (act) {
+#pragma unroll
+        for (int j = kTopK - 1; j >= 0; j--)
+          if (row[j] != kEmpty && !(claimed[row[j] >> 5] & (1u << (row[j] & 31)))) prop = (int)row[j];
+        dry = prop < 0;
+      }
+      if (act && prop >= 0) atomicMin(&minLane[prop & (kProjTab - 1)], (uint32_t)lane);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      // a lane is blocked by an earlier lane of this round hashing to the same slot (a false sharing only delays it)
+      const bool blocked = act && prop >= 0 && minLane[prop & (kProjTab - 1)] < (uint32_t)lane;
+      const bool rescan  = act && dry && truncated;
+      const unsigned long long stopMask = __ballot(blocked || rescan);
+      const int                f        = stopMask ? __ffsll((long long)stopMask) - 1 : 64;
+      const bool               commit   = act && lane < f;
+      if (commit && prop >= 0) {
+        atomicOr(&claimed[prop >> 5], 1u << (prop & 31));  // CurrentFrame.mvpMapPoints[bestIdx2] = pMP (:1789)
+        mine = prop;
+      }
+      if (act && prop >= 0) minLane[prop & (kProjTab - 1)] = 0xffu;  // every writer of a slot resets it
+      pending &= ~((f >= 64 ? ~0ull : ((1ull << f) - 1ull)) & pending);  // the prefix is decided (matched or dry for good)
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      if (f < 64 && ((__ballot(rescan) >> f) & 1ull)) {
+        // lane f is the first undecided point and its list ran dry: exact rescan of its window with the claim filter
+        const int       iq = c0 + f;
+        const ProjQuery q  = proj_query(a, iq);
         const ProjArgs& ar = a;
         const uint32_t* cl = claimed;
         uint32_t        out[kTopK];
-        int             nv;
+        int             nv2;
         wave_topk(
-            a.d1 + (size_t)i1 * 32, a.d2, 0, a.ng,
+            a.d1 + (size_t)iq * 32, a.d2, 0, a.ng,
             [&ar, &q, cl](int pos) {
               const int i2 = proj_candidate(ar, q, pos);
               return (i2 >= 0 && (cl[i2 >> 5] & (1u << (i2 & 31)))) ? -1 : i2;
             },
-            [thd = ar.thDist](int, int d) { return d <= thd; }, out, &nv);
-        if (out[0] != kEmpty) best2 = a.g_idx[out[0] & kPosMask];
-      }
-      if (best2 >= 0) {  // wave-uniform
-        if (lane == 0) {
-          claimed[best2 >> 5] |= 1u << (best2 & 31);  // CurrentFrame.mvpMapPoints[bestIdx2] = pMP (:1789)
-          a.m12[i1]    = best2;
-          a.m21[best2] = i1;
-          if (a.check_ori) {
-            const int bin = rot_bin(a.angle1[i1], a.kp2[best2].angle);
-            hist[bin]++;
-            a.binOf[i1] = bin;
+            [thd = ar.thDist](int, int d) { return d <= thd; }, out, &nv2);
+        if (out[0] != kEmpty) {
+          const int b = a.g_idx[out[0] & kPosMask];
+          if (lane == f) {
+            claimed[b >> 5] |= 1u << (b & 31);
+            mine = b;
           }
         }
-        nmatches++;
-        __syncthreads();
+        pending &= ~(1ull << f);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       }
     }
-    __syncthreads();
+    if (mine >= 0) {
+      a.m12[i1]   = mine;
+      a.m21[mine] = i1;
+      if (a.check_ori) {  // :1792-1809
+        const int bin = rot_bin(a.angle1[i1], a.kp2[mine].angle);
+        atomicAdd(&hist[bin], 1);
+        a.binOf[i1] = bin;
+      }
+    }
+    nmatches += __popcll(__ballot(mine >= 0));
   }
+  __syncthreads();
   if (a.check_ori) {  // :1889-1905
     int i1m, i2m, i3m;
     three_maxima(hist, kHistoLen, i1m, i2m, i3m);
@@ -989,9 +1019,44 @@ struct DBuf {
 
 }  // namespace
 
+// Host-pointer entry points are latency-bound: a dozen small hipMemcpyAsync calls cost more than the kernels.  The inputs of a
+// call are packed into one pinned staging block and go up with ONE copy; results come back the same way.
+struct Arena {
+  uint8_t *h = nullptr, *d = nullptr;
+  size_t   cap = 0, off = 0;
+  int      reserve(size_t bytes) {
+    off = 0;
+    if (bytes <= cap) return 0;
+    release();
+    if (hipHostMalloc((void**)&h, bytes, hipHostMallocDefault) != hipSuccess || hipMalloc((void**)&d, bytes) != hipSuccess) {
+      set_err("staging arena allocation failed");
+      release();
+      return -3;
+    }
+    cap = bytes;
+    return 0;
+  }
+  void release() {
+    if (h) hipHostFree(h);
+    if (d) hipFree(d);
+    h = d = nullptr, cap = off = 0;
+  }
+  template <class T>
+  T* put(const T* src, size_t n) {  // returns the DEVICE address; src == NULL just reserves
+    off   = (off + 15) & ~(size_t)15;
+    T* dp = reinterpret_cast<T*>(d + off);
+    if (src && n) memcpy(h + off, src, n * sizeof(T));
+    off += n * sizeof(T);
+    return dp;
+  }
+  template <class T>
+  const T* host_of(const T* dev_ptr) const { return reinterpret_cast<const T*>(h + (reinterpret_cast<const uint8_t*>(dev_ptr) - d)); }
+};
+
 struct orbm_matcher {
   int         device = 0;
   hipStream_t stream = nullptr;
+  Arena       in, out;
   DBuf<uint8_t>         dq, dt, dqv, dtv, gcx, gcy;
   DBuf<int>             qoff, qidx, toff, tidx, nvalid, binOf, mq, mt, nm, gidx, dbg;
   bool                  dbgOn = false;
@@ -1029,6 +1094,7 @@ void orbm_destroy(orbm_t* h) {
   h->qidx.release(), h->toff.release(), h->tidx.release(), h->nvalid.release(), h->binOf.release(), h->mq.release(), h->mt.release();
   h->nm.release(), h->gidx.release(), h->qa.release(), h->ta.release(), h->prev.release(), h->topk.release(), h->kp1.release();
   h->kp2.release(), h->dbg.release();
+  h->in.release(), h->out.release();
   delete h;
 }
 
@@ -1360,46 +1426,33 @@ int orbm_search_by_projection(orbm_t* h, const uint8_t* last_desc, const float* 
         gcy[p]      = (uint8_t)(cellOf[i] % kGridRows);
       }
   }
-  hipStream_t s = h->stream;
-  if (h->dq.ensure((size_t)n1 * 32 + 32) || h->dt.ensure((size_t)n2 * 32 + 32) || h->kp2.ensure(n2 + 1) || h->gidx.ensure(ng + 1) ||
-      h->gcx.ensure(ng + 1) || h->gcy.ensure(ng + 1) || h->prev.ensure((size_t)2 * n1 + 2) || h->qa.ensure((size_t)2 * n1 + 2) ||
-      h->ta.ensure((size_t)n2 + 66) || h->qoff.ensure(n1 + 1) || h->dqv.ensure(n1 + 1) || h->dtv.ensure(n2 + 1) ||
-      h->topk.ensure((size_t)(n1 + 1) * kTopK) || h->nvalid.ensure(n1 + 1) || h->binOf.ensure(n1 + 1) || h->mq.ensure(n1 + 1) ||
-      h->mt.ensure(n2 + 1) || h->nm.ensure(1))
+  hipStream_t  s  = h->stream;
+  const size_t inBytes = (size_t)n1 * (32 + 8 + 4 + 4 + 4 + 1) + (size_t)n2 * (32 + sizeof(orbx_keypoint_t) + 4 + 1) + (size_t)ng * 6 + 64 * 4 + 16 * 16;
+  const size_t outBytes = (size_t)(n1 + n2 + 4) * 4 + 64;
+  if (h->in.reserve(inBytes) || h->out.reserve(outBytes) || h->topk.ensure((size_t)(n1 + 1) * kTopK) || h->nvalid.ensure(n1 + 1) ||
+      h->binOf.ensure(n1 + 1))
     return -3;
-  auto up = [&](void* d, const void* src, size_t bytes) -> hipError_t {
-    return bytes ? hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, s) : hipSuccess;
-  };
-  // device layout: prev = uv; qa = [angle | invz]; ta = [scale factors (64) | uRight]; qoff = octaves; dqv / dtv = valid / occupied
-  HIP_TRYM(up(h->dq.p, last_desc, (size_t)n1 * 32));
-  HIP_TRYM(up(h->dt.p, cur_desc, (size_t)n2 * 32));
-  HIP_TRYM(up(h->kp2.p, cur_kp, (size_t)n2 * sizeof(orbx_keypoint_t)));
-  HIP_TRYM(up(h->gidx.p, gidx.data(), (size_t)ng * 4));
-  HIP_TRYM(up(h->gcx.p, gcx.data(), ng));
-  HIP_TRYM(up(h->gcy.p, gcy.data(), ng));
-  HIP_TRYM(up(h->prev.p, last_uv, (size_t)n1 * 8));
-  HIP_TRYM(up(h->qa.p, last_angle, (size_t)n1 * 4));
-  if (last_invz) HIP_TRYM(up(h->qa.p + n1, last_invz, (size_t)n1 * 4));
-  HIP_TRYM(up(h->ta.p, scale_factors, (size_t)nlevels * 4));
-  if (cur_u_right) HIP_TRYM(up(h->ta.p + 64, cur_u_right, (size_t)n2 * 4));
-  HIP_TRYM(up(h->qoff.p, last_octave, (size_t)n1 * 4));
-  if (last_valid) HIP_TRYM(up(h->dqv.p, last_valid, n1));
-  if (cur_occupied) HIP_TRYM(up(h->dtv.p, cur_occupied, n2));
   ProjArgs a;
   memset(&a, 0, sizeof(a));
-  a.d1 = h->dq.p, a.d2 = h->dt.p, a.uv = h->prev.p, a.invz = last_invz ? h->qa.p + n1 : nullptr, a.angle1 = h->qa.p, a.oct1 = h->qoff.p;
-  a.valid1 = last_valid ? h->dqv.p : nullptr, a.kp2 = h->kp2.p, a.uRight = cur_u_right ? h->ta.p + 64 : nullptr;
-  a.occupied = cur_occupied ? h->dtv.p : nullptr, a.n1 = n1, a.n2 = n2, a.ng = ng, a.g_idx = h->gidx.p, a.g_cx = h->gcx.p, a.g_cy = h->gcy.p;
-  a.sf = h->ta.p, a.th = th, a.mbf = mbf, a.minX = min_x, a.minY = min_y, a.gwInv = gwInv, a.ghInv = ghInv, a.dir = dir, a.thDist = th_dist;
-  a.check_ori = check_ori, a.topk = h->topk.p, a.nvalid = h->nvalid.p, a.m12 = h->mq.p, a.m21 = h->mt.p, a.binOf = h->binOf.p, a.nmatches = h->nm.p;
+  Arena& in = h->in;
+  a.d1 = in.put(last_desc, (size_t)n1 * 32), a.d2 = in.put(cur_desc, (size_t)n2 * 32), a.kp2 = in.put(cur_kp, n2);
+  a.g_idx = in.put(gidx.data(), ng), a.g_cx = in.put(gcx.data(), ng), a.g_cy = in.put(gcy.data(), ng);
+  a.uv = in.put(last_uv, (size_t)2 * n1), a.angle1 = in.put(last_angle, n1), a.invz = last_invz ? in.put(last_invz, n1) : nullptr;
+  a.sf = in.put(scale_factors, nlevels), a.uRight = cur_u_right ? in.put(cur_u_right, n2) : nullptr, a.oct1 = in.put(last_octave, n1);
+  a.valid1 = last_valid ? in.put(last_valid, n1) : nullptr, a.occupied = cur_occupied ? in.put(cur_occupied, n2) : nullptr;
+  HIP_TRYM(hipMemcpyAsync(in.d, in.h, in.off, hipMemcpyHostToDevice, s));
+  Arena& out = h->out;
+  a.nmatches = out.put((const int*)nullptr, 4), a.m12 = out.put((const int*)nullptr, n1), a.m21 = out.put((const int*)nullptr, n2);
+  a.n1 = n1, a.n2 = n2, a.ng = ng, a.th = th, a.mbf = mbf, a.minX = min_x, a.minY = min_y, a.gwInv = gwInv, a.ghInv = ghInv, a.dir = dir;
+  a.thDist = th_dist, a.check_ori = check_ori, a.topk = h->topk.p, a.nvalid = h->nvalid.p, a.binOf = h->binOf.p;
   if (n1 > 0) hipLaunchKernelGGL(k_proj_topk, dim3((n1 + 3) / 4), dim3(256), 0, s, a);
   hipLaunchKernelGGL(k_proj_resolve, dim3(1), dim3(64), 0, s, a);
   HIP_TRYM(hipGetLastError());
-  int nm = 0;
-  HIP_TRYM(hipMemcpyAsync(&nm, h->nm.p, 4, hipMemcpyDeviceToHost, s));
-  if (n1) HIP_TRYM(hipMemcpyAsync(cur_of_last, h->mq.p, (size_t)n1 * 4, hipMemcpyDeviceToHost, s));
-  if (n2 && last_of_cur) HIP_TRYM(hipMemcpyAsync(last_of_cur, h->mt.p, (size_t)n2 * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRYM(hipMemcpyAsync(out.h, out.d, out.off, hipMemcpyDeviceToHost, s));
   HIP_TRYM(hipStreamSynchronize(s));
+  const int nm = *out.host_of(a.nmatches);
+  if (n1) memcpy(cur_of_last, out.host_of(a.m12), (size_t)n1 * 4);
+  if (n2 && last_of_cur) memcpy(last_of_cur, out.host_of(a.m21), (size_t)n2 * 4);
   return nm;
 }
 

@@ -1,0 +1,120 @@
+"""Measurement of the SURVEY 8(f) rows built so far (N1 stereo matches, N2 BoW transform, N3 SearchByProjection): the device
+path against the CPU restatement (oracle, one thread) on the same inputs, on this box.  One JSON line per row.
+N1 / N3 are host-pointer, synchronous entry points (H2D + kernels + D2H per call); N2 is the device-batch entry point.
+Usage (GPU box): python tools/bench_next_rows.py > gpurun_out/next_rows.jsonl
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import oracle_py as O  # checker / CPU baseline only
+from orbslam3_cpp_fork_amd import synth
+from orbslam3_cpp_fork_amd.extractor import ComputeStereoMatches, ORBextractor
+from orbslam3_cpp_fork_amd.matcher import ORBmatcher
+from orbslam3_cpp_fork_amd.vocabulary import ORBVocabulary
+
+
+def timeit(fn, reps):
+    fn()
+    t = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    return (time.perf_counter() - t) / reps
+
+
+def row_n1():
+    h, w, nf = 376, 1241, 2000
+    left, right = synth.make_stereo_pair(h, w, camera_idx=5)
+    gl, gr = ORBextractor(nf), ORBextractor(nf)
+    _, kl, dl = gl(left, None, (0, 0))
+    _, kr, dr = gr(right, None, (0, 0))
+    ol, orr = O.OracleExtractor(nf), O.OracleExtractor(nf)
+    ol(left, (0, 0))
+    orr(right, (0, 0))
+    mb, mbf = 0.5372, 386.1448
+    ref = O.stereo_matches(ol, orr, kl, dl, kr, dr, mb, mbf)
+    got = ComputeStereoMatches(gl, gr, kl, dl, kr, dr, mb, mbf)
+    assert ref[0] == got[0] and (ref[1].view(np.uint32) == got[1].view(np.uint32)).all()
+    tg = timeit(lambda: ComputeStereoMatches(gl, gr, kl, dl, kr, dr, mb, mbf), 30)
+    tc = timeit(lambda: O.stereo_matches(ol, orr, kl, dl, kr, dr, mb, mbf), 10)
+    return {"row": "N1 Frame::ComputeStereoMatches", "workload": "1241x376 stereo pair, 2000 features per eye (%d / %d keypoints, %d matches)" % (len(kl), len(kr), ref[0]),
+            "gpu_ms_per_call": tg * 1e3, "cpu_oracle_ms_per_call": tc * 1e3, "speedup": tc / tg, "includes": "H2D of keypoints+descriptors, kernels, D2H (pyramids already resident)"}
+
+
+def row_n2():
+    B, rows, cols = 256, 480, 640
+    fr = synth.make_stream(rows, cols, B)
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.Stream()
+    torch.cuda.set_stream(st)
+    d = torch.from_numpy(fr).to(dev)
+    ex = ORBextractor(1000)
+    cap = ex.max_keypoints(rows, cols)
+    kps = torch.zeros((B, cap, 7), device=dev)
+    desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
+    cnt = torch.zeros((B, 2), dtype=torch.int32, device=dev)
+    ex.extract_batch_device(d, B, rows, cols, cols, rows * cols, kps, desc, cnt, cap, (0, 1000), stream=st.cuda_stream)
+    voc = synth.make_vocabulary(10, 6, seed=11)
+    gv = ORBVocabulary.from_arrays(10, 6, *voc)
+    ov = O.OracleVocabulary(10, 6, *voc)
+    out = {"bow_words": torch.zeros((B, cap), dtype=torch.int32, device=dev), "bow_vals": torch.zeros((B, cap), dtype=torch.float64, device=dev),
+           "n_words": torch.zeros(B, dtype=torch.int32, device=dev), "fv_nodes": torch.zeros((B, cap), dtype=torch.int32, device=dev),
+           "fv_off": torch.zeros((B, cap + 1), dtype=torch.int32, device=dev), "fv_feat": torch.zeros((B, cap), dtype=torch.int32, device=dev),
+           "n_nodes": torch.zeros(B, dtype=torch.int32, device=dev)}
+    for _ in range(3):
+        gv.transform_batch_device(desc, cnt, B, cap, 4, out, stream=st.cuda_stream)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(st)
+    for _ in range(10):
+        gv.transform_batch_device(desc, cnt, B, cap, 4, out, stream=st.cuda_stream)
+    e1.record(st)
+    torch.cuda.synchronize()
+    tg = e0.elapsed_time(e1) / 10 / B  # ms per frame
+    c = cnt.cpu().numpy()
+    D = desc.cpu().numpy()
+    # parity on a few frames, CPU time on 32 frames
+    for f in (0, 17, B - 1):
+        r = ov.transform(D[f, : c[f, 0]], 4)
+        nw = int(out["n_words"][f])
+        assert nw == len(r[0]) and out["bow_vals"][f, :nw].cpu().numpy().tobytes() == r[1].tobytes()
+    t = time.perf_counter()
+    for f in range(32):
+        ov.transform(D[f, : c[f, 0]], 4)
+    tc = (time.perf_counter() - t) / 32 * 1e3
+    return {"row": "N2 ORBVocabulary::transform", "workload": "256 VGA frames x %.0f descriptors, k=10 L=6 tree (1 111 110 nodes), levelsup 4" % c[:, 0].mean(),
+            "gpu_ms_per_frame": tg, "cpu_oracle_ms_per_frame": tc, "speedup": tc / tg, "includes": "device-resident batch (orbv_transform_batch_device), HIP events"}
+
+
+def row_n3():
+    frames = synth.make_stream(480, 640, 2, camera_idx=4)
+    oex = O.OracleExtractor(1000, 1.2, 8, 20, 7)
+    _, kA, dA = oex(frames[0], (0, 1000))
+    _, kB, dB = oex(frames[1], (0, 1000))
+    sf = oex.scale_tables()[0]
+    rng = np.random.default_rng(17)
+    _, mq, _ = O.match_groups(dA, dB, kA["angle"], kB["angle"], 50, 0.7, False, True)
+    ok = mq >= 0
+    shift = np.median(np.stack([kB["x"][mq[ok]] - kA["x"][ok], kB["y"][mq[ok]] - kA["y"][ok]], 1), axis=0)
+    uv = (np.stack([kA["x"], kA["y"]], 1) + shift + rng.normal(0, 3.0, (len(kA), 2))).astype(np.float32)
+    valid = ((uv[:, 0] >= 0) & (uv[:, 0] <= 640) & (uv[:, 1] >= 0) & (uv[:, 1] <= 480)).astype(np.uint8)
+    bounds = (0.0, 640.0, 0.0, 480.0)
+    m = ORBmatcher(0.9, True)
+    ref = O.search_by_projection(dA, uv, None, kA["octave"], kA["angle"], valid, dB, kB, None, None, sf, 15.0, 0, 0.0, bounds, 100, True)
+    got = m.SearchByProjection(dA, uv, kA["octave"], kA["angle"], kB, dB, sf, 15.0, bounds, last_valid=valid)
+    assert ref[0] == got[0] and ref[1].tolist() == got[1].tolist()
+    tg = timeit(lambda: m.SearchByProjection(dA, uv, kA["octave"], kA["angle"], kB, dB, sf, 15.0, bounds, last_valid=valid), 50)
+    tc = timeit(lambda: O.search_by_projection(dA, uv, None, kA["octave"], kA["angle"], valid, dB, kB, None, None, sf, 15.0, 0, 0.0, bounds, 100, True), 20)
+    return {"row": "N3 SearchByProjection(Frame, Frame)", "workload": "%d projected points vs %d features, th = 15, %d matches" % (len(kA), len(kB), ref[0]),
+            "gpu_ms_per_call": tg * 1e3, "cpu_oracle_ms_per_call": tc * 1e3, "speedup": tc / tg, "includes": "host grid build, H2D, 2 kernels, D2H"}
+
+
+if __name__ == "__main__":
+    for fn in (row_n1, row_n2, row_n3):
+        print(json.dumps(fn()), flush=True)
