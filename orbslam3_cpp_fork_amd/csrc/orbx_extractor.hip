@@ -93,7 +93,7 @@ struct orbx_extractor {
   int             capB     = 0;
   int             lastB    = 0;
   orbx::Bufs      bufs{};
-  DevBuf<uint8_t> dPyr, dBlur, dNCh, dStage, dDescOut;
+  DevBuf<uint8_t> dPyr, dBlur, dNCh, dStage, dRaw, dDescOut;
   DevBuf<int2>    dXtab, dYtab;
   DevBuf<int4>    dCellDesc;
   DevBuf<long long> dDbgT;
@@ -542,7 +542,7 @@ void orbx_destroy(orbx_t* h) {
   if (h->evValid)
     for (auto& slot : h->ev)
       for (auto& e : slot) hipEventDestroy(e);
-  h->dPyr.release(), h->dBlur.release(), h->dStage.release(), h->dDescOut.release(), h->dXtab.release(), h->dYtab.release();
+  h->dPyr.release(), h->dBlur.release(), h->dRaw.release(), h->dStage.release(), h->dDescOut.release(), h->dXtab.release(), h->dYtab.release();
   h->dCellDesc.release(), h->dCellOrder.release(), h->dCellSlot.release(), h->dCellCount.release(), h->dNodeOf.release(), h->dCellOffs.release();
   h->dD.release(), h->dDIndex.release(), h->dNCh.release(), h->dPushOff.release(), h->dMultiOff.release();
   h->dKeptRank.release(), h->dVA.release(), h->dVB.release(), h->dCandCount.release(), h->dLvlCount.release(), h->dOutIdx.release();
@@ -617,7 +617,16 @@ int orbx_extract(orbx_t* h, const uint8_t* img, int rows, int cols, size_t step_
   const int pitch = alignUp(cols, 64);
   if (h->dStage.ensure((size_t)pitch * rows) || h->dKpOut.ensure(need) || h->dDescOut.ensure((size_t)need * 32) || h->dCounts.ensure(2))
     return -3;
-  HIP_TRY(hipMemcpy2DAsync(h->dStage.p, pitch, img, step_bytes, cols, rows, hipMemcpyHostToDevice, h->stream));
+  // Host -> device as ONE linear copy (a pitched copy from pageable memory degenerates to a row-by-row transfer: 3 ms for a
+  // 1241-px-wide image), then, if the caller's step is not the 64-byte aligned pitch the kernels like, a device-side repitch.
+  if ((int)step_bytes == pitch) {
+    HIP_TRY(hipMemcpyAsync(h->dStage.p, img, (size_t)pitch * rows, hipMemcpyHostToDevice, h->stream));
+  } else {
+    const size_t rawBytes = step_bytes * (size_t)(rows - 1) + cols;
+    if (h->dRaw.ensure(rawBytes)) return -3;
+    HIP_TRY(hipMemcpyAsync(h->dRaw.p, img, rawBytes, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpy2DAsync(h->dStage.p, pitch, h->dRaw.p, step_bytes, cols, rows, hipMemcpyDeviceToDevice, h->stream));
+  }
   rc = h->run(h->dStage.p, 1, rows, cols, pitch, (size_t)pitch * rows, lap0, lap1, h->dKpOut.p, h->dDescOut.p, h->dCounts.p, need, h->stream);
   if (rc) return rc;
   int counts[2] = {0, 0};
