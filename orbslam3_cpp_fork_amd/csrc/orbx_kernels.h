@@ -584,7 +584,7 @@ __device__ __forceinline__ void octree_args(const Bufs& b, const FrameGeom& g, i
 
 // Carve the node-level arrays (and, if they fit, the point labels) out of `lds`.  Layout per node: 2 x OtNode (24),
 // childCnt/best (16), childIdx/sortbuf (8), seven 16-bit index arrays (14), nCh (1, padded to 2) = 64 bytes.
-__device__ __forceinline__ void ot_carve_lds(OtArgs* a, unsigned char* lds, int nodeCap, int ptsCap) {
+__device__ __forceinline__ void ot_carve_lds(OtArgs* a, unsigned char* lds, int nodeCap, bool withLabels) {
   unsigned char* p = lds;
   a->childCnt = reinterpret_cast<Int4*>(p), a->best = reinterpret_cast<unsigned long long*>(p), p += 16 * nodeCap;
   a->childIdx = reinterpret_cast<Idx4*>(p), a->sortbuf = reinterpret_cast<unsigned long long*>(p), p += 8 * nodeCap;
@@ -599,7 +599,7 @@ __device__ __forceinline__ void ot_carve_lds(OtArgs* a, unsigned char* lds, int 
   a->vA = q, q += nodeCap;
   a->vB = q, q += nodeCap;
   a->nCh = reinterpret_cast<uint8_t*>(q), q += nodeCap;
-  if (a->n <= ptsCap) a->nodeOf = q;
+  if (withLabels) a->nodeOf = q;
 }
 
 // ldsNodeCap: nodes the dynamic LDS block was sized for (0 = everything stays in global memory); ldsPtsCap: point labels.
@@ -641,8 +641,20 @@ __global__ __launch_bounds__(kOctThreads) void k_octree(Bufs b, FrameGeom g, int
   if (c.tid == 0) b.candCount[(long long)f * g.nlevels + level] = n;
   c.sync();
   a.n = n;
-  if (L.nodeCap <= ldsNodeCap) ot_carve_lds(&a, ldsDyn + kOctSortWork * 4, L.nodeCap, ldsPtsCap);
-  ot_distribute(c, a);
+  // Three inlined copies of the core, one per placement of its state: with the pointers' provenance fixed in each copy the
+  // compiler addresses LDS with ds_* instructions (a runtime choice between LDS and global pointers leaves it with flat_*
+  // accesses, which pay the flat-address path on every node-array access of this latency-bound kernel).
+  if (L.nodeCap <= ldsNodeCap) {
+    if (n <= ldsPtsCap) {
+      ot_carve_lds(&a, ldsDyn + kOctSortWork * 4, L.nodeCap, true);
+      ot_distribute(c, a);
+    } else {
+      ot_carve_lds(&a, ldsDyn + kOctSortWork * 4, L.nodeCap, false);
+      ot_distribute(c, a);
+    }
+  } else {
+    ot_distribute(c, a);
+  }
 }
 
 // stand-alone quadtree on caller-supplied candidates (parity hook)
