@@ -49,6 +49,12 @@ void orbx_get_features_per_level(const orbx_t* h, int* out);
 
 /* Upper bound on keypoints one image of this size can yield (sum over levels of max(N_l + 3, 4 nIni_l));
  * output buffers of orbx_extract* must hold at least this many entries. -2 if the size is unsupported. */
+/* Fuses the cv::resize(im, im, cv::Size(new_cols, new_rows)) that System::TrackMonocular / TrackStereo / TrackRGBD apply when
+ * the settings ask for it (src/System.cc:472-478; Camera.newWidth / newHeight) into the extractor: images of any other size
+ * are first resized on the device (same fixed-point INTER_LINEAR as the pyramid), and orbx_max_keypoints / the pyramid
+ * accessors then refer to the resized frame.  0, 0 disables.  Shrink factors up to 1.32 (x) / 1.4 (y). */
+int orbx_set_input_resize(orbx_t* h, int new_cols, int new_rows);
+
 int orbx_max_keypoints(orbx_t* h, int rows, int cols);
 
 /* ORBextractor::operator()(image, mask [ignored], keypoints, descriptors, vLappingArea)

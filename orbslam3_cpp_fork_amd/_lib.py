@@ -29,6 +29,7 @@ SIGNATURES = {
     "orbx_get_levels": (_i, [_vp]),
     "orbx_get_scale_tables": (None, [_vp, _vp, _vp, _vp, _vp]),
     "orbx_get_features_per_level": (None, [_vp, _vp]),
+    "orbx_set_input_resize": (_i, [_vp, _i, _i]),
     "orbx_max_keypoints": (_i, [_vp, _i, _i]),
     "orbx_extract": (_i, [_vp, _vp, _i, _i, _sz, _i, _i, _vp, _vp, _i, _ip]),
     "orbx_extract_batch_device": (_i, [_vp, _vp, _i, _i, _i, _sz, _sz, _i, _i, _vp, _vp, _vp, _i, _vp]),

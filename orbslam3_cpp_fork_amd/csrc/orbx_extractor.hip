@@ -65,6 +65,26 @@ struct DevBuf {
   }
 };
 
+// cv::resize INTER_LINEAR index + Q11 weight tables for one (source, destination) size pair (OpenCV resize.cpp)
+void buildResizeTables(int sw, int sh, int dw, int dh, std::vector<int2>& xt, std::vector<int2>& yt) {
+  const double scale_x = 1. / ((double)dw / sw), scale_y = 1. / ((double)dh / sh);
+  auto         q11 = [](float v) { return (int)(short)std::min(std::max(cvRoundF(v * 2048), -32768), 32767); };
+  for (int dx = 0; dx < dw; dx++) {
+    float fx = (float)((dx + 0.5) * scale_x - 0.5);
+    int   sx = cvFloorF(fx);
+    fx -= sx;
+    if (sx < 0) fx = 0, sx = 0;
+    if (sx >= sw - 1) fx = 0, sx = sw - 1;
+    xt.push_back(make_int2(sx, (q11(1.f - fx) & 0xffff) | (q11(fx) << 16)));
+  }
+  for (int dy = 0; dy < dh; dy++) {
+    float fy = (float)((dy + 0.5) * scale_y - 0.5);
+    int   sy = cvFloorF(fy);
+    fy -= sy;
+    yt.push_back(make_int2(sy, (q11(1.f - fy) & 0xffff) | (q11(fy) << 16)));
+  }
+}
+
 }  // namespace
 
 struct orbx_extractor {
@@ -110,6 +130,17 @@ struct orbx_extractor {
   int                        stagePitch = 0;
   int                        fastGrid   = 0;
 
+  // optional cv::resize of the input before extraction (System::TrackMonocular etc., src/System.cc:472-478)
+  int          preW = 0, preH = 0, preSrcW = 0, preSrcH = 0;
+  DevBuf<int2> dPreX, dPreY;
+  DevBuf<uint8_t> dPre;
+  bool resizing(int rows, int cols) const { return preW > 0 && (rows != preH || cols != preW); }
+  void effective(int rows, int cols, int* er, int* ec) const {
+    *er = resizing(rows, cols) ? preH : rows;
+    *ec = resizing(rows, cols) ? preW : cols;
+  }
+  int runResized(const uint8_t* d_imgs, int B, int rows, int cols, size_t step, size_t frameStride, int lap0, int lap1, orbx::KpRec* d_kps,
+                 uint8_t* d_desc, int* d_counts, int cap, hipStream_t s);
   int makeGeometry(int rows, int cols);
   int ensureWorkspace(int rows, int cols, int B);
   int run(const uint8_t* d_imgs, int B, int rows, int cols, size_t step, size_t frameStride, int lap0, int lap1, orbx::KpRec* d_kps,
@@ -212,25 +243,7 @@ int orbx_extractor::makeGeometry(int rows, int cols) {
     // cv::resize INTER_LINEAR tables (OpenCV resize.cpp)
     L.xtabOff = (int)xt.size();
     L.ytabOff = (int)yt.size();
-    if (l > 0) {
-      const int    sw = g.lv[l - 1].w, sh = g.lv[l - 1].h;
-      const double scale_x = 1. / ((double)L.w / sw), scale_y = 1. / ((double)L.h / sh);
-      auto         q11 = [](float v) { return (int)(short)std::min(std::max(cvRoundF(v * 2048), -32768), 32767); };
-      for (int dx = 0; dx < L.w; dx++) {
-        float fx = (float)((dx + 0.5) * scale_x - 0.5);
-        int   sx = cvFloorF(fx);
-        fx -= sx;
-        if (sx < 0) fx = 0, sx = 0;
-        if (sx >= sw - 1) fx = 0, sx = sw - 1;
-        xt.push_back(make_int2(sx, (q11(1.f - fx) & 0xffff) | (q11(fx) << 16)));
-      }
-      for (int dy = 0; dy < L.h; dy++) {
-        float fy = (float)((dy + 0.5) * scale_y - 0.5);
-        int   sy = cvFloorF(fy);
-        fy -= sy;
-        yt.push_back(make_int2(sy, (q11(1.f - fy) & 0xffff) | (q11(fy) << 16)));
-      }
-    }
+    if (l > 0) buildResizeTables(g.lv[l - 1].w, g.lv[l - 1].h, L.w, L.h, xt, yt);
   }
   g.totalCells     = cellBase;
   g.totalSlots     = slotBase;
@@ -340,6 +353,34 @@ int orbx_extractor::ensureWorkspace(int rows, int cols, int B) {
   b.vB = dVB.p, b.candCount = dCandCount.p, b.lvlKp = dLvlKp.p, b.lvlCount = dLvlCount.p, b.outIdx = dOutIdx.p;
   capB = B;
   return 0;
+}
+
+// Extraction of frames that System::Track* would first cv::resize to (preW, preH): the resize runs on the device with the
+// pyramid's own kernel body, then the normal pipeline takes the resized frames as its level 0.
+int orbx_extractor::runResized(const uint8_t* d_imgs, int B, int rows, int cols, size_t step, size_t frameStride, int lap0, int lap1,
+                               orbx::KpRec* d_kps, uint8_t* d_desc, int* d_counts, int cap, hipStream_t s) {
+  using namespace orbx;
+  if (!resizing(rows, cols)) return run(d_imgs, B, rows, cols, step, frameStride, lap0, lap1, d_kps, d_desc, d_counts, cap, s);
+  // footprint of a 128 x 16 destination tile must fit the LDS stage of resize_tile (176 x 24 source pixels)
+  if ((double)cols / preW * kRsTileW + 6 > kRsLdsW || (double)rows / preH * (kRsTileH - 1) + 3 > kRsLdsH - 1) {
+    g_err = "input resize: shrink factor above 1.32 (x) / 1.4 (y) is not supported";
+    return -2;
+  }
+  if (preSrcW != cols || preSrcH != rows) {
+    std::vector<int2> xt, yt;
+    buildResizeTables(cols, rows, preW, preH, xt, yt);
+    if (dPreX.ensure(xt.size() + 1) || dPreY.ensure(yt.size() + 1)) return -3;
+    HIP_TRY(hipMemcpy(dPreX.p, xt.data(), xt.size() * sizeof(int2), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dPreY.p, yt.data(), yt.size() * sizeof(int2), hipMemcpyHostToDevice));
+    preSrcW = cols, preSrcH = rows;
+  }
+  const int    pitch = alignUp(preW, 64);
+  const size_t fs    = (size_t)pitch * preH;
+  if (dPre.ensure(fs * B + 256)) return -3;
+  dim3 grid((preW + kRsTileW - 1) / kRsTileW, (preH + kRsTileH - 1) / kRsTileH, B);
+  hipLaunchKernelGGL(k_resize_input, grid, dim3(256), 0, s, d_imgs, (int)step, (long long)frameStride, cols, rows, dPre.p, pitch, (long long)fs, preW,
+                     preH, dPreX.p, dPreY.p);
+  return run(dPre.p, B, preH, preW, pitch, fs, lap0, lap1, d_kps, d_desc, d_counts, cap, s);
 }
 
 int orbx_extractor::run(const uint8_t* d_imgs, int B, int rows, int cols, size_t step, size_t frameStride, int lap0, int lap1,
@@ -542,7 +583,7 @@ void orbx_destroy(orbx_t* h) {
   if (h->evValid)
     for (auto& slot : h->ev)
       for (auto& e : slot) hipEventDestroy(e);
-  h->dPyr.release(), h->dBlur.release(), h->dRaw.release(), h->dStage.release(), h->dDescOut.release(), h->dXtab.release(), h->dYtab.release();
+  h->dPyr.release(), h->dBlur.release(), h->dRaw.release(), h->dPre.release(), h->dPreX.release(), h->dPreY.release(), h->dStage.release(), h->dDescOut.release(), h->dXtab.release(), h->dYtab.release();
   h->dCellDesc.release(), h->dCellOrder.release(), h->dCellSlot.release(), h->dCellCount.release(), h->dNodeOf.release(), h->dCellOffs.release();
   h->dD.release(), h->dDIndex.release(), h->dNCh.release(), h->dPushOff.release(), h->dMultiOff.release();
   h->dKeptRank.release(), h->dVA.release(), h->dVB.release(), h->dCandCount.release(), h->dLvlCount.release(), h->dOutIdx.release();
@@ -566,9 +607,16 @@ void orbx_get_features_per_level(const orbx_t* h, int* out) {
   for (int i = 0; i < h->nlevels; i++) out[i] = h->quota[i];
 }
 
+int orbx_set_input_resize(orbx_t* h, int new_cols, int new_rows) {
+  if (!h || new_cols < 0 || new_rows < 0 || ((new_cols == 0) != (new_rows == 0))) return -2;
+  h->preW = new_cols, h->preH = new_rows, h->preSrcW = h->preSrcH = 0;
+  return 0;
+}
+
 int orbx_max_keypoints(orbx_t* h, int rows, int cols) {
   if (!h) return -2;
   hipSetDevice(h->device);
+  h->effective(rows, cols, &rows, &cols);
   int rc = h->makeGeometry(rows, cols);
   if (rc) return rc < 0 ? rc : -2;
   return h->geom.totalKp;
@@ -587,14 +635,16 @@ int orbx_extract_batch_device(orbx_t* h, const uint8_t* d_imgs, int nframes, int
     return -2;
   }
   HIP_TRY(hipSetDevice(h->device));
-  int rc = h->makeGeometry(rows, cols);
+  int er, ec;
+  h->effective(rows, cols, &er, &ec);
+  int rc = h->makeGeometry(er, ec);
   if (rc) return rc;
   if (cap < h->geom.totalKp) {
     g_err = "output capacity below orbx_max_keypoints()";
     return -2;
   }
   hipStream_t s = stream ? (hipStream_t)stream : h->stream;
-  return h->run(d_imgs, nframes, rows, cols, step_bytes, frame_stride_bytes, lap0, lap1, (orbx::KpRec*)d_kps, d_desc, d_counts, cap, s);
+  return h->runResized(d_imgs, nframes, rows, cols, step_bytes, frame_stride_bytes, lap0, lap1, (orbx::KpRec*)d_kps, d_desc, d_counts, cap, s);
 }
 
 int orbx_extract(orbx_t* h, const uint8_t* img, int rows, int cols, size_t step_bytes, int lap0, int lap1, orbx_keypoint_t* kps,
@@ -607,7 +657,9 @@ int orbx_extract(orbx_t* h, const uint8_t* img, int rows, int cols, size_t step_
     return -2;
   }
   HIP_TRY(hipSetDevice(h->device));
-  int rc = h->makeGeometry(rows, cols);
+  int er, ec;
+  h->effective(rows, cols, &er, &ec);
+  int rc = h->makeGeometry(er, ec);
   if (rc) return rc;
   const int need = h->geom.totalKp;
   if (cap < need) {
@@ -627,7 +679,7 @@ int orbx_extract(orbx_t* h, const uint8_t* img, int rows, int cols, size_t step_
     HIP_TRY(hipMemcpyAsync(h->dRaw.p, img, rawBytes, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipMemcpy2DAsync(h->dStage.p, pitch, h->dRaw.p, step_bytes, cols, rows, hipMemcpyDeviceToDevice, h->stream));
   }
-  rc = h->run(h->dStage.p, 1, rows, cols, pitch, (size_t)pitch * rows, lap0, lap1, h->dKpOut.p, h->dDescOut.p, h->dCounts.p, need, h->stream);
+  rc = h->runResized(h->dStage.p, 1, rows, cols, pitch, (size_t)pitch * rows, lap0, lap1, h->dKpOut.p, h->dDescOut.p, h->dCounts.p, need, h->stream);
   if (rc) return rc;
   int counts[2] = {0, 0};
   HIP_TRY(hipMemcpyAsync(counts, h->dCounts.p, sizeof(counts), hipMemcpyDeviceToHost, h->stream));

@@ -80,20 +80,22 @@ __device__ __forceinline__ const uint8_t* level_raw(const Bufs& b, const FrameGe
 // with aligned 32-bit loads, then every thread produces 2 rows x 4 px from LDS bytes.
 constexpr int kRsTileW = 128, kRsTileH = 16, kRsLdsW = 176, kRsLdsH = 25;  // one spare LDS row: see the vertical tap below
 
-__global__ __launch_bounds__(256) void k_resize_level(Bufs b, FrameGeom g, int level) {
+// One 128 x 16 destination tile of cv::resize(INTER_LINEAR).  S / sp / sw / sh: source image of this frame; D / dp / dw / dh:
+// destination; xtab / ytab: the host-built index + Q11 weight tables of this (source, destination) size pair.
+// CLAMP_ROWS: the second source row may clamp onto the first with a non-zero weight (cv::resize keeps fy at the top and bottom
+// rows when it enlarges); the pyramid only shrinks (scale > 1), where row sy + 1 always exists, and skips the test.
+template <bool CLAMP_ROWS>
+__device__ __forceinline__ void resize_tile(const uint8_t* __restrict__ S, int sp, int sw, int sh, uint8_t* __restrict__ D, int dp, int dw, int dh,
+                                            const int2* __restrict__ xtab, const int2* __restrict__ ytab) {
   __shared__ __align__(16) uint8_t src[kRsLdsH][kRsLdsW];
-  const LevelGeom& L   = g.lv[level];
-  const LevelGeom& Ls  = g.lv[level - 1];
-  const int        f   = blockIdx.z, tid = threadIdx.x;
+  const int        tid = threadIdx.x;
   const int        dx0 = blockIdx.x * kRsTileW, dy0 = blockIdx.y * kRsTileH;
-  const int        dxl = min(dx0 + kRsTileW, L.w) - 1, dyl = min(dy0 + kRsTileH, L.h) - 1;
-  int              sp;
-  const uint8_t*   S   = level_raw(b, g, level - 1, f, &sp);
+  const int        dxl = min(dx0 + kRsTileW, dw) - 1, dyl = min(dy0 + kRsTileH, dh) - 1;
   // source footprint of the tile (tables are monotone)
-  const int sxa = b.xtab[L.xtabOff + dx0].x & ~3;
-  const int sxb = min(b.xtab[L.xtabOff + dxl].x + 1, Ls.w - 1);
-  const int sya = min(max(b.ytab[L.ytabOff + dy0].x, 0), Ls.h - 1);
-  const int syb = min(max(b.ytab[L.ytabOff + dyl].x + 1, 0), Ls.h - 1);
+  const int sxa = xtab[dx0].x & ~3;
+  const int sxb = min(xtab[dxl].x + 1, sw - 1);
+  const int sya = min(max(ytab[dy0].x, 0), sh - 1);
+  const int syb = min(max(ytab[dyl].x + 1, 0), sh - 1);
   const int nw4 = (sxb - sxa + 4) >> 2, nrow = syb - sya + 1;  // <= 44 dwords x 24 rows
   const bool al4 = ((sp & 3) == 0) && ((reinterpret_cast<uintptr_t>(S) & 3) == 0);
   {  // staging: thread = (dword column tid % 64; rows tid / 64, +4, ...): no index division.  The loads are unconditional
@@ -105,7 +107,7 @@ __global__ __launch_bounds__(256) void k_resize_level(Bufs b, FrameGeom g, int l
 #pragma unroll
       for (int it = 0; it < 6; it++) {
         const int r = min((tid >> 6) + 4 * it, nrow - 1);
-        v[it]       = *reinterpret_cast<const uint32_t*>(S + (long long)(sya + r) * sp + sxa + c);  // may run past Ls.w inside the aligned row
+        v[it]       = *reinterpret_cast<const uint32_t*>(S + (long long)(sya + r) * sp + sxa + c);  // may run past sw inside the aligned row
       }
     } else {
 #pragma unroll
@@ -114,7 +116,7 @@ __global__ __launch_bounds__(256) void k_resize_level(Bufs b, FrameGeom g, int l
         const uint8_t* p = S + (long long)(sya + r) * sp + sxa + c;
         v[it]            = 0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) v[it] |= (uint32_t)p[min(k, Ls.w - 1 - sxa - c)] << (8 * k);
+        for (int k = 0; k < 4; k++) v[it] |= (uint32_t)p[min(k, sw - 1 - sxa - c)] << (8 * k);
       }
     }
 #pragma unroll
@@ -125,14 +127,14 @@ __global__ __launch_bounds__(256) void k_resize_level(Bufs b, FrameGeom g, int l
   }
   __syncthreads();
   const int dx = dx0 + (tid & 31) * 4;
-  if (dx >= L.w) return;
+  if (dx >= dw) return;
   // The four taps of a pixel sit at LDS offsets {0, 1, row, row + 1} from ONE address.  Where cv::resize clamps the second
   // column / row to the last source column / row its weight is 0 (fx = 0 / fy = 0 there), so the unclamped neighbour --
   // a stale byte of the LDS row, or the spare LDS row -- is read and multiplied by 0.
   int sx[4], a0[4], a1[4];
 #pragma unroll
   for (int k = 0; k < 4; k++) {
-    const int2 xt = b.xtab[L.xtabOff + min(dx + k, L.w - 1)];
+    const int2 xt = xtab[min(dx + k, dw - 1)];
     sx[k] = xt.x - sxa;
     a0[k] = (short)(xt.y & 0xffff);
     a1[k] = xt.y >> 16;
@@ -140,9 +142,10 @@ __global__ __launch_bounds__(256) void k_resize_level(Bufs b, FrameGeom g, int l
 #pragma unroll
   for (int rr = 0; rr < 2; rr++) {
     const int dy = dy0 + (tid >> 5) * 2 + rr;
-    if (dy >= L.h) break;
-    const int2 yt = b.ytab[L.ytabOff + dy];
-    const int  r0 = min(max(yt.x, 0), Ls.h - 1) - sya;
+    if (dy >= dh) break;
+    const int2 yt = ytab[dy];
+    const int  r0 = min(max(yt.x, 0), sh - 1) - sya;
+    const int  r1 = CLAMP_ROWS ? min(max(yt.x + 1, 0), sh - 1) - sya : r0 + 1;
     const int  b0 = (short)(yt.y & 0xffff), b1 = yt.y >> 16;
     uint32_t   out = 0;
 #pragma unroll
@@ -154,13 +157,30 @@ __global__ __launch_bounds__(256) void k_resize_level(Bufs b, FrameGeom g, int l
       int       c1 = c + 1;
       asm volatile("" : "+v"(c1));
       const int h0 = src[r0][c] * a0[k] + src[r0][c1] * a1[k];
-      const int h1 = src[r0 + 1][c] * a0[k] + src[r0 + 1][c1] * a1[k];
+      const int h1 = src[r1][c] * a0[k] + src[r1][c1] * a1[k];
       const int      v  = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
       out |= (uint32_t)(v & 0xff) << (8 * k);
     }
-    // pitch is a multiple of 64: lanes past L.w write into the row's padding
-    *reinterpret_cast<uint32_t*>(b.pyr + (long long)f * g.pyrBytes + L.pyrOff + (long long)dy * L.pitch + dx) = out;
+    // the destination pitch is a multiple of 64: lanes past dw write into the row's padding
+    *reinterpret_cast<uint32_t*>(D + (long long)dy * dp + dx) = out;
   }
+}
+
+__global__ __launch_bounds__(256) void k_resize_level(Bufs b, FrameGeom g, int level) {
+  const LevelGeom& L  = g.lv[level];
+  const LevelGeom& Ls = g.lv[level - 1];
+  int              sp;
+  const uint8_t*   S = level_raw(b, g, level - 1, blockIdx.z, &sp);
+  resize_tile<false>(S, sp, Ls.w, Ls.h, b.pyr + (long long)blockIdx.z * g.pyrBytes + L.pyrOff, L.pitch, L.w, L.h, b.xtab + L.xtabOff,
+                     b.ytab + L.ytabOff);
+}
+
+// cv::resize(im, im, cv::Size(newWidth, newHeight)) of System::TrackMonocular / TrackStereo / TrackRGBD (src/System.cc:472-478 and
+// siblings) before the extractor sees the image: same arithmetic, any size pair.
+__global__ __launch_bounds__(256) void k_resize_input(const uint8_t* __restrict__ src, int sp, long long srcFrameStride, int sw, int sh,
+                                                      uint8_t* __restrict__ dst, int dp, long long dstFrameStride, int dw, int dh,
+                                                      const int2* __restrict__ xtab, const int2* __restrict__ ytab) {
+  resize_tile<true>(src + (long long)blockIdx.z * srcFrameStride, sp, sw, sh, dst + (long long)blockIdx.z * dstFrameStride, dp, dw, dh, xtab, ytab);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -59,6 +59,10 @@ class ORBextractor:
         _lib.lib().orbx_get_features_per_level(self._h, ptr(a))
         return a
 
+    def set_input_resize(self, new_cols, new_rows):
+        """cv::resize(im, im, Size(new_cols, new_rows)) of System::Track* (src/System.cc:472-478) fused in front of the extractor; 0, 0 = off."""
+        check(_lib.lib().orbx_set_input_resize(self._h, int(new_cols), int(new_rows)), "orbx_set_input_resize")
+
     def max_keypoints(self, rows, cols):
         return check(_lib.lib().orbx_max_keypoints(self._h, rows, cols), "orbx_max_keypoints")
 
