@@ -180,6 +180,16 @@ int orbm_search_by_projection(orbm_t* h, const uint8_t* last_desc, const float* 
                               const float* scale_factors, int nlevels, float th, int dir, float mbf, float min_x, float max_x,
                               float min_y, float max_y, int th_dist, int check_ori, int* cur_of_last, int* last_of_cur);
 
+/* Frame::UndistortKeyPoints (src/Frame.cc:886-913): cv::undistortPoints(pts, pts, K, mDistCoef, cv::Mat(), mK)
+ * on the keypoint coordinates -- OpenCV's five fixed-point iterations in double precision -- every other field copied.
+ * K = {fx, fy, cx, cy}; dist = k1 k2 p1 p2 [k3 ...] (ndist <= 12); dist[0] == 0 copies the keypoints, as the reference does.
+ * The device form works on the buffers of orbx_extract_batch_device (d_counts may be NULL: all cap records); enqueue only. */
+int orbx_undistort_keypoints(orbx_t* h, const orbx_keypoint_t* kps, int n, const float K[4], const float* dist, int ndist, orbx_keypoint_t* out);
+int orbx_undistort_keypoints_device(orbx_t* h, const orbx_keypoint_t* d_kps, const int* d_counts, int nframes, int cap, const float K[4],
+                                    const float* dist, int ndist, orbx_keypoint_t* d_out, void* stream);
+/* Frame::ComputeImageBounds (src/Frame.cc:915-943): out = {mnMinX, mnMaxX, mnMinY, mnMaxY}; host arithmetic, same core. */
+int orbx_image_bounds(int cols, int rows, const float K[4], const float* dist, int ndist, float out[4]);
+
 /* ---------------------------------------------------------------------------------------------------------
  * ORBVocabulary::transform -- DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB> as
  * Frame::ComputeBoW uses it (src/Frame.cc:879-884), for the configuration of ORBvoc.txt (scoring L1_NORM, weighting

@@ -299,6 +299,30 @@ def search_by_projection(last_desc, last_uv, last_invz, last_octave, last_angle,
     return n, col, loc
 
 
+def undistort_keypoints(kps, K, dist):
+    """Frame::UndistortKeyPoints: K = (fx, fy, cx, cy), dist = (k1, k2, p1, p2[, k3])."""
+    kps = np.ascontiguousarray(kps, KP_DTYPE)
+    K = np.ascontiguousarray(K, np.float32)
+    dist = np.ascontiguousarray(dist, np.float32)
+    out = np.zeros(len(kps), KP_DTYPE)
+    L = lib()
+    L.orao_undistort_keypoints.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    L.orao_undistort_keypoints.restype = None
+    L.orao_undistort_keypoints(_p(kps), len(kps), _p(K), _p(dist), len(dist), _p(out))
+    return out
+
+
+def image_bounds(cols, rows, K, dist):
+    K = np.ascontiguousarray(K, np.float32)
+    dist = np.ascontiguousarray(dist, np.float32)
+    out = np.zeros(4, np.float32)
+    L = lib()
+    L.orao_image_bounds.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    L.orao_image_bounds.restype = None
+    L.orao_image_bounds(cols, rows, _p(K), _p(dist), len(dist), _p(out))
+    return out
+
+
 class OracleVocabulary:
     """ORBVocabulary (DBoW2 TemplatedVocabulary, TF_IDF / L1_NORM) restated on the CPU: transform()."""
 

@@ -1173,6 +1173,88 @@ int orao_match_window(const uint8_t* d1, const orao_keypoint_t* kp1, int n1, con
 }
 
 
+// cv::undistortPoints for one CV_32FC2 point (OpenCV >= 4.5 undistort.dispatch.cpp, cvUndistortPointsInternal), criteria =
+// TermCriteria(MAX_ITER, 5, 0.01), R empty, P = the 3x3 new camera matrix.
+static void cv_undistort_point(const double A[3][3], const double k[14], const double PP[3][3], float sx, float sy, float* dx, float* dy) {
+  double RR[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+  {  // cvMatMul(&_PP, &_RR, &_RR)
+    double T[3][3];
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) {
+        double acc = 0;
+        for (int t = 0; t < 3; t++) acc += PP[i][t] * RR[t][j];
+        T[i][j] = acc;
+      }
+    memcpy(RR, T, sizeof(T));
+  }
+  const double fx = A[0][0], fy = A[1][1], ifx = 1. / fx, ify = 1. / fy, cx = A[0][2], cy = A[1][2];
+  double       x = sx, y = sy, x0, y0;
+  const double u = x, v = y;
+  x = (x - cx) * ifx;
+  y = (y - cy) * ify;
+  {  // invMatTilt = identity
+    const double vu0 = 1. * x + 0. * y + 0. * 1, vu1 = 0. * x + 1. * y + 0. * 1, vu2 = 0. * x + 0. * y + 1. * 1;
+    const double invProj = vu2 ? 1. / vu2 : 1;
+    x0 = x = invProj * vu0;
+    y0 = y = invProj * vu1;
+  }
+  for (int j = 0;; j++) {
+    if (j >= 5) break;
+    const double r2     = x * x + y * y;
+    const double icdist = (1 + ((k[7] * r2 + k[6]) * r2 + k[5]) * r2) / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2);
+    if (icdist < 0) {
+      x = (u - cx) * ifx;
+      y = (v - cy) * ify;
+      break;
+    }
+    const double deltaX = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x) + k[8] * r2 + k[9] * r2 * r2;
+    const double deltaY = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y + k[10] * r2 + k[11] * r2 * r2;
+    x                   = (x0 - deltaX) * icdist;
+    y                   = (y0 - deltaY) * icdist;
+  }
+  const double xx = RR[0][0] * x + RR[0][1] * y + RR[0][2];
+  const double yy = RR[1][0] * x + RR[1][1] * y + RR[1][2];
+  const double ww = 1. / (RR[2][0] * x + RR[2][1] * y + RR[2][2]);
+  *dx             = (float)(xx * ww);
+  *dy             = (float)(yy * ww);
+}
+
+static void cam_matrices(const float K[4], const float* dist, int ndist, double A[3][3], double k[14]) {
+  const double a[3][3] = {{K[0], 0, K[2]}, {0, K[1], K[3]}, {0, 0, 1}};
+  memcpy(A, a, sizeof(a));
+  for (int i = 0; i < 14; i++) k[i] = 0;
+  for (int i = 0; i < ndist && i < 14; i++) k[i] = dist[i];
+}
+
+void orao_undistort_keypoints(const orao_keypoint_t* kps, int n, const float K[4], const float* dist, int ndist, orao_keypoint_t* out) {
+  if (ndist < 1 || dist[0] == 0.0) {  // mDistCoef.at<float>(0) == 0.0 (src/Frame.cc:887)
+    memcpy(out, kps, sizeof(orao_keypoint_t) * n);
+    return;
+  }
+  double A[3][3], k[14];
+  cam_matrices(K, dist, ndist, A, k);
+  for (int i = 0; i < n; i++) {
+    out[i] = kps[i];
+    cv_undistort_point(A, k, A, kps[i].x, kps[i].y, &out[i].x, &out[i].y);
+  }
+}
+
+void orao_image_bounds(int cols, int rows, const float K[4], const float* dist, int ndist, float out[4]) {
+  if (ndist >= 1 && dist[0] != 0.0) {
+    double A[3][3], k[14];
+    cam_matrices(K, dist, ndist, A, k);
+    const float src[4][2] = {{0.f, 0.f}, {(float)cols, 0.f}, {0.f, (float)rows}, {(float)cols, (float)rows}};
+    float       m[4][2];
+    for (int i = 0; i < 4; i++) cv_undistort_point(A, k, A, src[i][0], src[i][1], &m[i][0], &m[i][1]);
+    out[0] = std::min(m[0][0], m[2][0]);
+    out[1] = std::max(m[1][0], m[3][0]);
+    out[2] = std::min(m[0][1], m[1][1]);
+    out[3] = std::max(m[2][1], m[3][1]);
+  } else {
+    out[0] = 0.0f, out[1] = (float)cols, out[2] = 0.0f, out[3] = (float)rows;
+  }
+}
+
 // SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, th, bMono) (src/ORBmatcher.cc:1684-1908), Nleft == -1
 int orao_search_by_projection(const uint8_t* last_desc, const float* last_uv, const float* last_invz, const int* last_octave,
                               const float* last_angle, const uint8_t* last_valid, int n1, const uint8_t* cur_desc,

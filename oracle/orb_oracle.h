@@ -123,6 +123,13 @@ int orao_search_by_projection(const uint8_t* last_desc, const float* last_uv, co
                               const float* scale_factors, float th, int dir, float mbf, float min_x, float max_x, float min_y,
                               float max_y, int th_dist, int check_ori, int* cur_of_last, int* last_of_cur);
 
+/* Frame::UndistortKeyPoints (src/Frame.cc:886-913): cv::undistortPoints(mat, mat, K, mDistCoef, cv::Mat(), mK) on the keypoint
+ * coordinates (OpenCV cvUndistortPointsInternal, 5 iterations, doubles); K = (fx, fy, cx, cy) floats, dist = k1 k2 p1 p2 [k3]
+ * floats (ndist = 4 or 5).  dist[0] == 0 copies the keypoints (:887-890).  The other KeyPoint fields are copied. */
+void orao_undistort_keypoints(const orao_keypoint_t* kps, int n, const float K[4], const float* dist, int ndist, orao_keypoint_t* out);
+/* Frame::ComputeImageBounds (src/Frame.cc:915-943): out = {mnMinX, mnMaxX, mnMinY, mnMaxY}. */
+void orao_image_bounds(int cols, int rows, const float K[4], const float* dist, int ndist, float out[4]);
+
 /* ---- DBoW2 vocabulary tree: ORBVocabulary::transform (N2) ----
  * TemplatedVocabulary<FORB::TDescriptor, FORB> restated for the configuration ORB-SLAM3 ships (ORBvoc.txt header
  * "10 6 0 0": scoring L1_NORM, weighting TF_IDF).  Node i + 1 of the tree is entry i of the arrays (node 0 = root), in the

@@ -33,6 +33,9 @@ SIGNATURES = {
     "orbx_max_keypoints": (_i, [_vp, _i, _i]),
     "orbx_extract": (_i, [_vp, _vp, _i, _i, _sz, _i, _i, _vp, _vp, _i, _ip]),
     "orbx_extract_batch_device": (_i, [_vp, _vp, _i, _i, _i, _sz, _sz, _i, _i, _vp, _vp, _vp, _i, _vp]),
+    "orbx_undistort_keypoints": (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp]),
+    "orbx_undistort_keypoints_device": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _vp]),
+    "orbx_image_bounds": (_i, [_i, _i, _vp, _vp, _i, _vp]),
     "orbx_stereo_matches": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _f, _f, _vp, _vp]),
     "orbx_pyramid_level": (_i, [_vp, _i, _i, _vp, _sz, _ip, _ip]),
     "orbx_set_profiling": (None, [_vp, _i]),

@@ -783,6 +783,61 @@ int orbx_debug_octree_device(orbx_t* h, const uint32_t* cand, int n, int W, int 
   return 0;
 }
 
+static orbx::UndistortParams undistortParams(const float K[4], const float* dist, int ndist) {
+  orbx::UndistortParams p;
+  p.fx = K[0], p.fy = K[1], p.cx = K[2], p.cy = K[3];  // cvConvert(float -> double)
+  for (int i = 0; i < 12; i++) p.k[i] = i < ndist ? (double)dist[i] : 0.0;
+  p.pfx = p.fx, p.pfy = p.fy, p.pcx = p.cx, p.pcy = p.cy;  // P = mK
+  return p;
+}
+
+// Frame::ComputeImageBounds (src/Frame.cc:915-943): four corners through the same arithmetic, on the host.
+int orbx_image_bounds(int cols, int rows, const float K[4], const float* dist, int ndist, float out[4]) {
+  if (!K || !out || ndist < 0 || ndist > 12 || (ndist > 0 && !dist)) return -2;
+  if (ndist >= 1 && dist[0] != 0.0) {
+    const orbx::UndistortParams p = undistortParams(K, dist, ndist);
+    const float                 src[4][2] = {{0.f, 0.f}, {(float)cols, 0.f}, {0.f, (float)rows}, {(float)cols, (float)rows}};
+    float                       m[4][2];
+    for (int i = 0; i < 4; i++) orbx::undistort_point(p, src[i][0], src[i][1], &m[i][0], &m[i][1]);
+    out[0] = std::min(m[0][0], m[2][0]);
+    out[1] = std::max(m[1][0], m[3][0]);
+    out[2] = std::min(m[0][1], m[1][1]);
+    out[3] = std::max(m[2][1], m[3][1]);
+  } else {
+    out[0] = 0.0f, out[1] = (float)cols, out[2] = 0.0f, out[3] = (float)rows;
+  }
+  return 0;
+}
+
+int orbx_undistort_keypoints_device(orbx_t* h, const orbx_keypoint_t* d_kps, const int* d_counts, int nframes, int cap, const float K[4],
+                                    const float* dist, int ndist, orbx_keypoint_t* d_out, void* stream) {
+  if (!h || !d_kps || !d_out || !K || nframes < 0 || cap < 0 || ndist < 0 || ndist > 12 || (ndist > 0 && !dist)) return -2;
+  if (nframes == 0 || cap == 0) return 0;
+  HIP_TRY(hipSetDevice(h->device));
+  hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+  if (ndist < 1 || dist[0] == 0.0) {  // mvKeysUn = mvKeys (src/Frame.cc:887-890)
+    if (d_out != d_kps) HIP_TRY(hipMemcpyAsync(d_out, d_kps, (size_t)nframes * cap * sizeof(orbx_keypoint_t), hipMemcpyDeviceToDevice, s));
+    return 0;
+  }
+  hipLaunchKernelGGL(orbx::k_undistort, dim3((cap + 255) / 256, nframes), dim3(256), 0, s, (const orbx::KpRec*)d_kps, d_counts, cap,
+                     undistortParams(K, dist, ndist), (orbx::KpRec*)d_out);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int orbx_undistort_keypoints(orbx_t* h, const orbx_keypoint_t* kps, int n, const float K[4], const float* dist, int ndist, orbx_keypoint_t* out) {
+  if (!h || n < 0 || (n > 0 && (!kps || !out)) || !K) return -2;
+  if (n == 0) return 0;
+  HIP_TRY(hipSetDevice(h->device));
+  if (h->dKpOut.ensure((size_t)2 * n)) return -3;
+  HIP_TRY(hipMemcpyAsync(h->dKpOut.p, kps, (size_t)n * sizeof(orbx_keypoint_t), hipMemcpyHostToDevice, h->stream));
+  int rc = orbx_undistort_keypoints_device(h, (const orbx_keypoint_t*)h->dKpOut.p, nullptr, 1, n, K, dist, ndist, (orbx_keypoint_t*)(h->dKpOut.p + n), h->stream);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(out, h->dKpOut.p + n, (size_t)n * sizeof(orbx_keypoint_t), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
 // Frame::ComputeStereoMatches (reference src/Frame.cc:944-1113).  Both handles must have extracted an image of the same
 // size with their single-frame orbx_extract (the pyramids of that call are still resident on the device).
 int orbx_stereo_matches(orbx_t* left, orbx_t* right, const orbx_keypoint_t* kl, const uint8_t* dl, int nl, const orbx_keypoint_t* kr,

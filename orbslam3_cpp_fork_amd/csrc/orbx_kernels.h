@@ -19,6 +19,7 @@
 #include "octree_core.h"
 #include "orb_sincosf_port.h"
 #include "orbx_geom.h"
+#include "undistort_core.h"
 
 namespace orbx {
 
@@ -1317,6 +1318,20 @@ __global__ __launch_bounds__(256) void k_stereo_cut(StereoArgs a, int* kept) {
   atomicAdd(&sCount, keep);
   __syncthreads();
   if (tid == 0) *kept = sCount;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Frame::UndistortKeyPoints (src/Frame.cc:886-913): one thread per keypoint, cv::undistortPoints in doubles (undistort_core.h);
+// every other KeyPoint field is copied.  counts == NULL: all `cap` records of every frame.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_undistort(const KpRec* __restrict__ kps, const int* __restrict__ counts, int cap, UndistortParams p,
+                                                   KpRec* __restrict__ out) {
+  const int f = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+  const int n = counts ? counts[2 * f] : cap;
+  if (i >= n) return;
+  KpRec k = kps[(long long)f * cap + i];
+  undistort_point(p, k.x, k.y, &k.x, &k.y);
+  out[(long long)f * cap + i] = k;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -145,6 +145,25 @@ class ORBextractor:
         return dict(zip(_lib.STAGE_NAMES, ms.tolist()))
 
 
+def UndistortKeyPoints(ex, keys, K, dist):
+    """Frame::UndistortKeyPoints (src/Frame.cc:886-913): keys (KP_DTYPE) -> mvKeysUn; K = (fx, fy, cx, cy), dist = (k1, k2, p1, p2[, k3])."""
+    k = np.ascontiguousarray(keys, KP_DTYPE)
+    Kf = np.ascontiguousarray(K, np.float32)
+    d = np.ascontiguousarray(dist, np.float32)
+    out = np.zeros(len(k), KP_DTYPE)
+    check(_lib.lib().orbx_undistort_keypoints(ex._h, ptr(k), len(k), ptr(Kf), ptr(d), len(d), ptr(out)), "orbx_undistort_keypoints")
+    return out
+
+
+def ComputeImageBounds(cols, rows, K, dist):
+    """Frame::ComputeImageBounds (src/Frame.cc:915-943) -> (mnMinX, mnMaxX, mnMinY, mnMaxY)."""
+    Kf = np.ascontiguousarray(K, np.float32)
+    d = np.ascontiguousarray(dist, np.float32)
+    out = np.zeros(4, np.float32)
+    check(_lib.lib().orbx_image_bounds(int(cols), int(rows), ptr(Kf), ptr(d), len(d), ptr(out)), "orbx_image_bounds")
+    return tuple(float(v) for v in out)
+
+
 def ComputeStereoMatches(ex_left, ex_right, keys_left, desc_left, keys_right, desc_right, mb, mbf):
     """Frame::ComputeStereoMatches (reference src/Frame.cc:944-1113) on the pyramids the two extractors hold on the device
     after their last single-image call.  Returns (n_kept, mvuRight, mvDepth)."""

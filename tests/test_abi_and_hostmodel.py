@@ -152,3 +152,16 @@ def test_sincos_port_exhaustive(oracle):
     c1, s1 = np.zeros_like(deg), np.zeros_like(deg)
     _lib.lib().orbx_debug_sincos_deg(deg.ctypes.data_as(C.c_void_p), len(deg), c1.ctypes.data_as(C.c_void_p), s1.ctypes.data_as(C.c_void_p))
     assert (c0.view(np.uint32) == c1.view(np.uint32)).all() and (s0.view(np.uint32) == s1.view(np.uint32)).all()
+
+
+def test_image_bounds_host(oracle):
+    """orbx_image_bounds is host arithmetic over the core shared with the device kernel (undistort_core.h): checked against the
+    oracle's separate restatement of cv::undistortPoints without a GPU."""
+    from orbslam3_cpp_fork_amd.extractor import ComputeImageBounds
+
+    for K, dist, (w, h) in (
+        ([458.654, 457.296, 367.215, 248.375], [-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05], (752, 480)),
+        ([517.306408, 516.469215, 318.643040, 255.313989], [0.262383, -0.953104, -0.005358, 0.002628, 1.163314], (640, 480)),
+        ([718.856, 718.856, 607.1928, 185.2157], [0.0, 0.0, 0.0, 0.0], (1241, 376)),
+    ):
+        assert list(ComputeImageBounds(w, h, K, dist)) == oracle.image_bounds(w, h, K, dist).tolist()

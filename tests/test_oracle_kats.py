@@ -414,3 +414,38 @@ def test_search_by_projection_kat(oracle):
     # window is open: |dx| < r.  Feature 1 at x = 104 is 3 px from u = 101: r = 3 excludes it (and keeps feature 0 at 1 px)
     n, col, _ = oracle.search_by_projection(last_desc[:1], uv[:1], None, octv[:1], ang[:1], None, dcur[1:2], cur[1:2], None, None, sf, 3.0, 0, 0.0, bounds, 100, False)
     assert n == 0
+
+
+def _distort(xn, yn, K, dist):
+    """Forward plumb-bob model (what the lens does): normalised undistorted -> pixel."""
+    k1, k2, p1, p2 = dist[:4]
+    k3 = dist[4] if len(dist) > 4 else 0.0
+    r2 = xn * xn + yn * yn
+    rad = 1 + k1 * r2 + k2 * r2 * r2 + k3 * r2 ** 3
+    xd = xn * rad + 2 * p1 * xn * yn + p2 * (r2 + 2 * xn * xn)
+    yd = yn * rad + p1 * (r2 + 2 * yn * yn) + 2 * p2 * xn * yn
+    return K[0] * xd + K[2], K[1] * yd + K[3]
+
+
+def test_undistort_kats(oracle):
+    """Frame::UndistortKeyPoints / ComputeImageBounds (src/Frame.cc:886-943) restated on cv::undistortPoints' fixed-point iteration."""
+    K = [458.654, 457.296, 367.215, 248.375]  # EuRoC cam0
+    dist = [-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05]
+    kp = np.zeros(5, oracle.KP_DTYPE)
+    kp["x"], kp["y"] = [367.215, 300.0, 420.5, 200.25, 500.0], [248.375, 200.0, 300.25, 310.0, 150.0]
+    kp["octave"], kp["angle"], kp["response"] = [0, 1, 2, 3, 4], [1, 2, 3, 4, 5], [9, 8, 7, 6, 5]
+    un = oracle.undistort_keypoints(kp, K, dist)
+    assert (un["x"][0], un["y"][0]) == (np.float32(367.215), np.float32(248.375))  # the principal point is a fixed point
+    for f in ("size", "angle", "response", "octave", "class_id"):
+        assert (un[f] == kp[f]).all()
+    # consistency with the lens model: distorting the undistorted point gives the pixel back (5 iterations converge near the centre)
+    for i in range(5):
+        xn, yn = (float(un["x"][i]) - K[2]) / K[0], (float(un["y"][i]) - K[3]) / K[1]
+        xd, yd = _distort(xn, yn, K, dist)
+        assert abs(xd - kp["x"][i]) < 2e-3 and abs(yd - kp["y"][i]) < 2e-3
+    # no distortion: mvKeysUn = mvKeys, bounds = the image
+    assert oracle.undistort_keypoints(kp, K, [0.0, 0.1, 0.0, 0.0]).tobytes() == kp.tobytes()
+    assert oracle.image_bounds(752, 480, K, [0.0, 0.0, 0.0, 0.0]).tolist() == [0.0, 752.0, 0.0, 480.0]
+    # barrel distortion (k1 < 0): the undistorted image extends beyond the frame on every side
+    b = oracle.image_bounds(752, 480, K, dist)
+    assert b[0] < 0 and b[1] > 752 and b[2] < 0 and b[3] > 480
