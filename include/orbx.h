@@ -190,6 +190,26 @@ int orbx_undistort_keypoints_device(orbx_t* h, const orbx_keypoint_t* d_kps, con
 /* Frame::ComputeImageBounds (src/Frame.cc:915-943): out = {mnMinX, mnMaxX, mnMinY, mnMaxY}; host arithmetic, same core. */
 int orbx_image_bounds(int cols, int rows, const float K[4], const float* dist, int ndist, float out[4]);
 
+/* Frame::AssignFeaturesToGrid (src/Frame.cc:524-553) for every frame of an extraction batch, on the device: the (undistorted)
+ * keypoints that fall inside the 64 x 48 grid over [min_x, max_x] x [min_y, max_y], in the scan order of GetFeaturesInArea
+ * (cells (ix, iy) ascending, feature index ascending inside a cell).  Frame f writes d_g_idx / d_g_cx / d_g_cy at [f * cap ..]
+ * (feature index, cell column, cell row) and d_ng[f].  cap <= 8192.  Enqueue only. */
+int orbm_assign_features_to_grid_device(orbm_t* h, const orbx_keypoint_t* d_kps_un, const int* d_counts, int nframes, int cap, float min_x,
+                                        float max_x, float min_y, float max_y, int* d_g_idx, uint8_t* d_g_cx, uint8_t* d_g_cy, int* d_ng,
+                                        void* stream);
+/* orbm_search_by_projection for npairs (last frame, current frame) pairs of one extraction batch, device-resident: d_desc /
+ * d_kps_un / d_counts / cap are the batch buffers (keypoints undistorted); d_pairs = npairs x {last, current} frame indices;
+ * the per-pair inputs d_last_uv [npairs][cap][2], d_last_invz, d_last_valid, d_occupied [npairs][cap] and the optional
+ * d_last_desc [npairs][cap][32] (MapPoint descriptors; NULL = the last frame's own descriptors) follow the single-pair
+ * meanings; d_u_right is [nframes][cap] or NULL.  The grid is built on the device.  Pair p writes d_cur_of_last /
+ * d_last_of_cur at [p * cap ..] and d_nmatches[p].  scale_factors is a host array.  Enqueue only. */
+int orbm_search_by_projection_batch_device(orbm_t* h, int npairs, const int* d_pairs, const uint8_t* d_desc, const orbx_keypoint_t* d_kps_un,
+                                           const int* d_counts, int nframes, int cap, const uint8_t* d_last_desc, const float* d_last_uv,
+                                           const float* d_last_invz, const uint8_t* d_last_valid, const float* d_u_right,
+                                           const uint8_t* d_occupied, const float* scale_factors, int nlevels, float th, int dir, float mbf,
+                                           float min_x, float max_x, float min_y, float max_y, int th_dist, int check_ori, int* d_cur_of_last,
+                                           int* d_last_of_cur, int* d_nmatches, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * ORBVocabulary::transform -- DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB> as
  * Frame::ComputeBoW uses it (src/Frame.cc:879-884), for the configuration of ORBvoc.txt (scoring L1_NORM, weighting

@@ -790,7 +790,35 @@ struct ProjArgs {
   uint32_t*              topk;
   int*                   nvalid;
   int *                  m12, *m21, *binOf, *nmatches;
+  // batch form (pairs != NULL): blockIdx.y = pair p = {last frame, current frame} of one extraction batch ([frames][cap] buffers);
+  // per-pair arrays are [npairs][cap]; the grid arrays come from k_assign_grid ([frames][cap], ngOf[frames])
+  const int*             pairs;
+  const int*             counts;
+  const int*             ngOf;
+  const orbx_keypoint_t* kp1;  // last frame's keypoints: octave and angle are read from here when set
+  int                    cap, hasLastDesc;
 };
+
+__device__ __forceinline__ ProjArgs proj_view(const ProjArgs& a, int p) {
+  if (!a.pairs) return a;
+  ProjArgs     v  = a;
+  const int    fl = a.pairs[2 * p], fc = a.pairs[2 * p + 1];
+  const size_t pc = (size_t)p * a.cap, lc = (size_t)fl * a.cap, cc = (size_t)fc * a.cap;
+  v.d1     = a.hasLastDesc ? a.d1 + pc * 32 : a.d2 + lc * 32;
+  v.d2     = a.d2 + cc * 32;
+  v.uv     = a.uv + pc * 2;
+  v.invz   = a.invz ? a.invz + pc : nullptr;
+  v.valid1 = a.valid1 ? a.valid1 + pc : nullptr;
+  v.kp1    = a.kp2 + lc;
+  v.kp2    = a.kp2 + cc;
+  v.uRight = a.uRight ? a.uRight + cc : nullptr;
+  v.occupied = a.occupied ? a.occupied + pc : nullptr;
+  v.n1 = a.counts[2 * fl], v.n2 = a.counts[2 * fc], v.ng = a.ngOf[fc];
+  v.g_idx = a.g_idx + cc, v.g_cx = a.g_cx + cc, v.g_cy = a.g_cy + cc;
+  v.topk = a.topk + pc * kTopK, v.nvalid = a.nvalid + pc, v.m12 = a.m12 + pc, v.m21 = a.m21 + pc, v.binOf = a.binOf + pc;
+  v.nmatches = a.nmatches + p;
+  return v;
+}
 
 struct ProjQuery {
   float u, v, r, invz;
@@ -802,7 +830,7 @@ __device__ __forceinline__ ProjQuery proj_query(const ProjArgs& a, int i) {
   ProjQuery q;
   q.u = a.uv[2 * i], q.v = a.uv[2 * i + 1];
   q.invz      = a.invz ? a.invz[i] : 0.f;
-  const int o = a.oct1[i];
+  const int o = a.kp1 ? a.kp1[i].octave : a.oct1[i];
   q.r         = a.th * a.sf[o];  // :1736
   if (a.dir == 1)
     q.minL = o, q.maxL = -1;  // bForward: GetFeaturesInArea(u, v, radius, nLastOctave)
@@ -840,8 +868,9 @@ __device__ __forceinline__ int proj_candidate(const ProjArgs& a, const ProjQuery
   return i2;
 }
 
-__global__ __launch_bounds__(256) void k_proj_topk(ProjArgs a) {
-  const int i1 = blockIdx.x * 4 + (threadIdx.x >> 6);
+__global__ __launch_bounds__(256) void k_proj_topk(ProjArgs a0) {
+  const ProjArgs a  = proj_view(a0, blockIdx.y);
+  const int      i1 = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i1 >= a.n1) return;
   uint32_t out[kTopK];
   int      nv = 0;
@@ -863,6 +892,51 @@ __global__ __launch_bounds__(256) void k_proj_topk(ProjArgs a) {
   }
 }
 
+// Frame::AssignFeaturesToGrid / PosInGrid (src/Frame.cc:524-553, 867-877) for every frame of a batch: the features that fall in
+// the 64 x 48 grid, listed in the scan order of GetFeaturesInArea (cell (ix, iy) ascending, feature index ascending inside).
+// One workgroup per frame; keys cell << 16 | index bitonic-sorted in LDS (NP = power of two >= cap, <= 8192).
+__global__ __launch_bounds__(256) void k_assign_grid(const orbx_keypoint_t* __restrict__ kps, const int* __restrict__ counts, int cap, int NP,
+                                                     float minX, float minY, float gwInv, float ghInv, int* __restrict__ g_idx,
+                                                     uint8_t* __restrict__ g_cx, uint8_t* __restrict__ g_cy, int* __restrict__ ngOf) {
+  extern __shared__ uint32_t gridKeys[];
+  __shared__ int             sCount;
+  const int                  f = blockIdx.x, tid = threadIdx.x;
+  const int                  n = min(counts ? counts[2 * f] : cap, NP);
+  if (tid == 0) sCount = 0;
+  __syncthreads();
+  int mine = 0;
+  for (int p = tid; p < NP; p += 256) {
+    uint32_t key = 0xffffffffu;
+    if (p < n) {
+      const orbx_keypoint_t kp = kps[(size_t)f * cap + p];
+      const int posX = (int)roundf((kp.x - minX) * gwInv), posY = (int)roundf((kp.y - minY) * ghInv);
+      if (!(posX < 0 || posX >= kGridCols || posY < 0 || posY >= kGridRows)) key = ((uint32_t)(posX * kGridRows + posY) << 16) | (uint32_t)p, mine++;
+    }
+    gridKeys[p] = key;
+  }
+  if (mine) atomicAdd(&sCount, mine);
+  for (int k = 2; k <= NP; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      __syncthreads();
+      for (int t = tid; t < (NP >> 1); t += 256) {
+        const int      lo = 2 * t - (t & (j - 1)), hi = lo + j;
+        const bool     up = (lo & k) == 0;
+        const uint32_t x = gridKeys[lo], y = gridKeys[hi];
+        if ((x > y) == up) gridKeys[lo] = y, gridKeys[hi] = x;
+      }
+    }
+  __syncthreads();
+  const int ng = sCount;
+  for (int p = tid; p < ng; p += 256) {
+    const uint32_t key  = gridKeys[p];
+    const int      cell = (int)(key >> 16);
+    g_idx[(size_t)f * cap + p] = (int)(key & 0xffffu);
+    g_cx[(size_t)f * cap + p]  = (uint8_t)(cell / kGridRows);
+    g_cy[(size_t)f * cap + p]  = (uint8_t)(cell % kGridRows);
+  }
+  if (tid == 0) ngOf[f] = ng;
+}
+
 // The reference walks the points one by one; a point's choice only depends on which features EARLIER points took.  The wave
 // takes 64 consecutive points (lane = point, its 8-deep list in registers) and runs rounds: every undecided lane proposes its
 // first feature not yet taken; the proposals of the lanes before the first CONFLICT (a lane proposing what an earlier lane of
@@ -871,7 +945,8 @@ __global__ __launch_bounds__(256) void k_proj_topk(ProjArgs a) {
 // retries.  A lane whose list ran dry although more candidates exist stops the prefix and is rescanned exactly.
 constexpr int kProjTab = 1024;  // proposal table (earliest proposing lane per hashed feature)
 
-__global__ __launch_bounds__(64) void k_proj_resolve(ProjArgs a) {
+__global__ __launch_bounds__(64) void k_proj_resolve(ProjArgs a0) {
+  const ProjArgs      a = proj_view(a0, blockIdx.x);
   __shared__ uint32_t claimed[kMaxTrainW / 32];
   __shared__ uint32_t minLane[kProjTab];
   __shared__ int      hist[kHistoLen];
@@ -954,7 +1029,7 @@ __global__ __launch_bounds__(64) void k_proj_resolve(ProjArgs a) {
       a.m12[i1]   = mine;
       a.m21[mine] = i1;
       if (a.check_ori) {  // :1792-1809
-        const int bin = rot_bin(a.angle1[i1], a.kp2[mine].angle);
+        const int bin = rot_bin(a.kp1 ? a.kp1[i1].angle : a.angle1[i1], a.kp2[mine].angle);
         atomicAdd(&hist[bin], 1);
         a.binOf[i1] = bin;
       }
@@ -1454,6 +1529,69 @@ int orbm_search_by_projection(orbm_t* h, const uint8_t* last_desc, const float* 
   if (n1) memcpy(cur_of_last, out.host_of(a.m12), (size_t)n1 * 4);
   if (n2 && last_of_cur) memcpy(last_of_cur, out.host_of(a.m21), (size_t)n2 * 4);
   return nm;
+}
+
+// Frame::AssignFeaturesToGrid for the frames of an extraction batch, device-resident (see k_assign_grid).
+int orbm_assign_features_to_grid_device(orbm_t* h, const orbx_keypoint_t* d_kps_un, const int* d_counts, int nframes, int cap, float min_x,
+                                        float max_x, float min_y, float max_y, int* d_g_idx, uint8_t* d_g_cx, uint8_t* d_g_cy, int* d_ng,
+                                        void* stream) {
+  if (!h || !d_kps_un || !d_g_idx || !d_g_cx || !d_g_cy || !d_ng || nframes < 0 || cap < 1 || !(max_x > min_x) || !(max_y > min_y)) return -2;
+  if (cap > 8192) {
+    set_err("orbm_assign_features_to_grid_device: more than 8192 features per frame");
+    return -2;
+  }
+  if (nframes == 0) return 0;
+  HIP_TRYM(hipSetDevice(h->device));
+  int NP = 256;
+  while (NP < cap) NP <<= 1;
+  const float gwInv = static_cast<float>(kGridCols) / (max_x - min_x), ghInv = static_cast<float>(kGridRows) / (max_y - min_y);
+  hipLaunchKernelGGL(k_assign_grid, dim3(nframes), dim3(256), (size_t)NP * 4, stream ? (hipStream_t)stream : h->stream, d_kps_un, d_counts, cap, NP,
+                     min_x, min_y, gwInv, ghInv, d_g_idx, d_g_cx, d_g_cy, d_ng);
+  HIP_TRYM(hipGetLastError());
+  return 0;
+}
+
+// SearchByProjection(CurrentFrame, LastFrame, th, bMono) for many (last, current) frame pairs of one extraction batch; everything
+// stays on the device (see include/orbx.h).  Enqueue only.
+int orbm_search_by_projection_batch_device(orbm_t* h, int npairs, const int* d_pairs, const uint8_t* d_desc, const orbx_keypoint_t* d_kps_un,
+                                           const int* d_counts, int nframes, int cap, const uint8_t* d_last_desc, const float* d_last_uv,
+                                           const float* d_last_invz, const uint8_t* d_last_valid, const float* d_u_right,
+                                           const uint8_t* d_occupied, const float* scale_factors, int nlevels, float th, int dir, float mbf,
+                                           float min_x, float max_x, float min_y, float max_y, int th_dist, int check_ori, int* d_cur_of_last,
+                                           int* d_last_of_cur, int* d_nmatches, void* stream) {
+  if (!h || npairs < 0 || !d_pairs || !d_desc || !d_kps_un || !d_counts || nframes < 1 || cap < 1 || !d_last_uv || !scale_factors ||
+      nlevels < 1 || nlevels > 64 || dir < 0 || dir > 2 || !(max_x > min_x) || !(max_y > min_y) || !d_cur_of_last || !d_last_of_cur ||
+      !d_nmatches || (d_u_right && !d_last_invz)) {
+    set_err("orbm_search_by_projection_batch_device: bad arguments");
+    return -2;
+  }
+  if (cap > 8192) {
+    set_err("orbm_search_by_projection_batch_device: more than 8192 features per frame");
+    return -2;
+  }
+  if (npairs == 0) return 0;
+  HIP_TRYM(hipSetDevice(h->device));
+  hipStream_t  s  = stream ? (hipStream_t)stream : h->stream;
+  const size_t fc = (size_t)nframes * cap, pc = (size_t)npairs * cap;
+  if (h->gidx.ensure(fc) || h->gcx.ensure(fc) || h->gcy.ensure(fc) || h->qoff.ensure(nframes + 1) || h->ta.ensure(64) ||
+      h->topk.ensure(pc * kTopK) || h->nvalid.ensure(pc) || h->binOf.ensure(pc))
+    return -3;
+  int rc = orbm_assign_features_to_grid_device(h, d_kps_un, d_counts, nframes, cap, min_x, max_x, min_y, max_y, h->gidx.p, h->gcx.p, h->gcy.p,
+                                               h->qoff.p, s);
+  if (rc) return rc;
+  HIP_TRYM(hipMemcpyAsync(h->ta.p, scale_factors, (size_t)nlevels * 4, hipMemcpyHostToDevice, s));
+  ProjArgs a;
+  memset(&a, 0, sizeof(a));
+  a.pairs = d_pairs, a.counts = d_counts, a.ngOf = h->qoff.p, a.cap = cap, a.hasLastDesc = d_last_desc ? 1 : 0;
+  a.d1 = d_last_desc, a.d2 = d_desc, a.kp2 = d_kps_un, a.uv = d_last_uv, a.invz = d_last_invz, a.valid1 = d_last_valid;
+  a.uRight = d_u_right, a.occupied = d_occupied, a.g_idx = h->gidx.p, a.g_cx = h->gcx.p, a.g_cy = h->gcy.p, a.sf = h->ta.p;
+  a.th = th, a.mbf = mbf, a.minX = min_x, a.minY = min_y, a.gwInv = static_cast<float>(kGridCols) / (max_x - min_x);
+  a.ghInv = static_cast<float>(kGridRows) / (max_y - min_y), a.dir = dir, a.thDist = th_dist, a.check_ori = check_ori;
+  a.topk = h->topk.p, a.nvalid = h->nvalid.p, a.binOf = h->binOf.p, a.m12 = d_cur_of_last, a.m21 = d_last_of_cur, a.nmatches = d_nmatches;
+  hipLaunchKernelGGL(k_proj_topk, dim3((cap + 3) / 4, npairs), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_proj_resolve, dim3(npairs), dim3(64), 0, s, a);
+  HIP_TRYM(hipGetLastError());
+  return 0;
 }
 
 }  // extern "C"

@@ -158,3 +158,86 @@ def test_search_by_projection(oracle, direction, stereo, th):
     got = ORBmatcher(0.9, True).SearchByProjection(dA2, uv, kA["octave"], kA["angle"], kB, dB2, sf, 60.0, bounds, last_valid=valid, last_invz=invz,
                                                    cur_u_right=ur, cur_occupied=occ, direction=0, mbf=mbf)
     assert got[0] == ref[0] and got[1].tolist() == ref[1].tolist() and got[2].tolist() == ref[2].tolist()
+
+
+def test_grid_and_projection_batch_device(oracle):
+    """Device-resident forms: AssignFeaturesToGrid (k_assign_grid) against a float32 numpy restatement of PosInGrid, and
+    SearchByProjection for consecutive frame pairs of one extraction batch against the oracle, pair by pair."""
+    import ctypes as C
+
+    import torch
+
+    from orbslam3_cpp_fork_amd import _lib
+    from orbslam3_cpp_fork_amd import synth as S
+    from orbslam3_cpp_fork_amd.extractor import ORBextractor
+    from orbslam3_cpp_fork_amd.matcher import ORBmatcher
+
+    B, rows, cols = 4, 480, 640
+    fr = S.make_stream(rows, cols, B, camera_idx=2)
+    ex = ORBextractor(1000)
+    cap = ex.max_keypoints(rows, cols)
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.current_stream().cuda_stream
+    d = torch.from_numpy(fr).to(dev)
+    kps = torch.zeros((B, cap, 7), device=dev)
+    desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
+    cnt = torch.zeros((B, 2), dtype=torch.int32, device=dev)
+    ex.extract_batch_device(d, B, rows, cols, cols, rows * cols, kps, desc, cnt, cap, (0, 1000), stream=st)
+    torch.cuda.synchronize()
+    c = cnt.cpu().numpy()
+    K = [np.frombuffer(kps[f, : c[f, 0]].cpu().numpy().tobytes(), oracle.KP_DTYPE) for f in range(B)]
+    D = [desc[f, : c[f, 0]].cpu().numpy() for f in range(B)]
+    m = ORBmatcher(0.9, True)
+    L = _lib.lib()
+    bounds = (0.0, float(cols), 0.0, float(rows))
+    # ---- grid
+    gi = torch.zeros((B, cap), dtype=torch.int32, device=dev)
+    gx = torch.zeros((B, cap), dtype=torch.uint8, device=dev)
+    gy = torch.zeros((B, cap), dtype=torch.uint8, device=dev)
+    ng = torch.zeros(B, dtype=torch.int32, device=dev)
+    assert L.orbm_assign_features_to_grid_device(m._h, _lib.ptr(kps), _lib.ptr(cnt), B, cap, *bounds, _lib.ptr(gi), _lib.ptr(gx), _lib.ptr(gy), _lib.ptr(ng), st) == 0
+    torch.cuda.synchronize()
+    gw, gh = np.float32(64) / np.float32(cols), np.float32(48) / np.float32(rows)
+    for f in range(B):
+        # std::round (half away from zero) on non-negative float32 products
+        px = np.floor((K[f]["x"] * gw).astype(np.float32) + np.float32(0.5)).astype(np.int64)
+        py = np.floor((K[f]["y"] * gh).astype(np.float32) + np.float32(0.5)).astype(np.int64)
+        ok = (px >= 0) & (px < 64) & (py >= 0) & (py < 48)
+        order = sorted(np.nonzero(ok)[0].tolist(), key=lambda i: (px[i], py[i], i))
+        n = int(ng[f])
+        assert n == len(order)
+        assert gi[f, :n].cpu().numpy().tolist() == order
+        assert gx[f, :n].cpu().numpy().tolist() == px[order].tolist() and gy[f, :n].cpu().numpy().tolist() == py[order].tolist()
+    # ---- batched SearchByProjection over the pairs (f - 1, f)
+    P = B - 1
+    pairs = np.stack([np.arange(P), np.arange(1, B)], 1).astype(np.int32)
+    sf = oracle.OracleExtractor(1000, 1.2, 8, 20, 7).scale_tables()[0]
+    rng = np.random.default_rng(5)
+    uv = np.zeros((P, cap, 2), np.float32)
+    valid = np.zeros((P, cap), np.uint8)
+    occ = (rng.random((P, cap)) < 0.05).astype(np.uint8)
+    for p in range(P):
+        a, b = K[p], K[p + 1]
+        _, mq, _ = oracle.match_groups(D[p], D[p + 1], a["angle"], b["angle"], 50, 0.7, False, True)
+        okm = mq >= 0
+        shift = np.median(np.stack([b["x"][mq[okm]] - a["x"][okm], b["y"][mq[okm]] - a["y"][okm]], 1), axis=0)
+        n1 = len(a)
+        uv[p, :n1] = np.stack([a["x"], a["y"]], 1) + shift + rng.normal(0, 2.0, (n1, 2))
+        valid[p, :n1] = ((uv[p, :n1, 0] >= 0) & (uv[p, :n1, 0] <= cols) & (uv[p, :n1, 1] >= 0) & (uv[p, :n1, 1] <= rows)).astype(np.uint8)
+    t = lambda x: torch.from_numpy(x).to(dev)
+    d_pairs, d_uv, d_valid, d_occ = t(pairs), t(uv), t(valid), t(occ)
+    col = torch.zeros((P, cap), dtype=torch.int32, device=dev)
+    loc = torch.zeros((P, cap), dtype=torch.int32, device=dev)
+    nm = torch.zeros(P, dtype=torch.int32, device=dev)
+    sfc = np.ascontiguousarray(sf, np.float32)
+    rc = L.orbm_search_by_projection_batch_device(m._h, P, _lib.ptr(d_pairs), _lib.ptr(desc), _lib.ptr(kps), _lib.ptr(cnt), B, cap, None, _lib.ptr(d_uv), None,
+                                                  _lib.ptr(d_valid), None, _lib.ptr(d_occ), _lib.ptr(sfc), len(sfc), 15.0, 0, 0.0, *bounds, 100, 1,
+                                                  _lib.ptr(col), _lib.ptr(loc), _lib.ptr(nm), st)
+    assert rc == 0
+    torch.cuda.synchronize()
+    for p in range(P):
+        a, b = K[p], K[p + 1]
+        n1, n2 = len(a), len(b)
+        ref = oracle.search_by_projection(D[p], uv[p, :n1], None, a["octave"], a["angle"], valid[p, :n1], D[p + 1], b, None, occ[p, :n2], sf, 15.0, 0, 0.0, bounds, 100, True)
+        assert int(nm[p]) == ref[0] and ref[0] > 100
+        assert col[p, :n1].cpu().numpy().tolist() == ref[1].tolist() and loc[p, :n2].cpu().numpy().tolist() == ref[2].tolist()
