@@ -91,6 +91,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-match", action="store_true", help="extract only")
     ap.add_argument("--lanes", type=int, default=1, help="chunks in flight (each on its own HIP stream and handles)")
+    ap.add_argument("--bow", action="store_true", help="SearchByBoW proper: add ORBVocabulary::transform (synthetic k=10, L=6 tree) per frame and match "
+                    "inside the FeatureVector groups instead of brute force (not the BASELINE configuration; reported as its own workload)")
     args = ap.parse_args()
 
     import torch
@@ -128,6 +130,12 @@ def main():
     pairs = np.stack([(np.arange(B) - 1) % B, np.arange(B)], 1).astype(np.int32)  # frame f-1 (query) vs frame f (train)
     d_pairs = torch.from_numpy(pairs).to(dev)
 
+    voc = None
+    if args.bow and not args.no_match:
+        from orbslam3_cpp_fork_amd.vocabulary import ORBVocabulary
+
+        voc = ORBVocabulary.from_arrays(10, 6, *synth.make_vocabulary(10, 6, seed=11), device=local_rank)
+
     class Lane:
         """One in-flight chunk: its own extractor / matcher handles, output buffers and HIP stream.  Consecutive steps
         alternate between the lanes, so chunk i+1's throughput-bound kernels run beside chunk i's latency-bound ones
@@ -148,6 +156,12 @@ def main():
             self.gather = shard.RecordGather(B, self.cap, dev, world, rank, host_staged=(backend != "nccl")) if world > 1 else None
             self.pending = None
             self.match_ev = []
+            self.bow_ev = []
+            if voc is not None:
+                z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)
+                self.bow = {"bow_words": z((B, self.cap), torch.int32), "bow_vals": z((B, self.cap), torch.float64), "n_words": z(B, torch.int32),
+                            "fv_nodes": z((B, self.cap), torch.int32), "fv_off": z((B, self.cap + 1), torch.int32), "fv_feat": z((B, self.cap), torch.int32),
+                            "n_nodes": z(B, torch.int32)}
 
         def step(self, timed=False):
             with torch.cuda.stream(self.tstream):
@@ -156,10 +170,26 @@ def main():
                     self.pending = None
                 self.ex.extract_batch_device(d_imgs, B, rows, cols, cols, rows * cols, self.d_kps, self.d_desc, self.d_cnt, self.cap, (0, 1000), stream=self.stream)
                 if not args.no_match:
+                    if voc is not None:
+                        if timed:
+                            b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                            b0.record()
+                        voc.transform_batch_device(self.d_desc, self.d_cnt, B, self.cap, 4, self.bow, stream=self.stream)
+                        if timed:
+                            b1.record()
+                            self.bow_ev.append((b0, b1))
                     if timed:
                         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                         e0.record()
-                    self.mt.match_pairs_device(self.d_desc, self.d_kps, self.d_cnt, self.cap, d_pairs, B, self.d_match, self.d_nm, stream=self.stream)
+                    if voc is not None:
+                        from orbslam3_cpp_fork_amd import _lib as _L
+
+                        rc = _L.lib().orbm_match_pairs_bow_device(self.mt._h, _L.ptr(self.d_desc), _L.ptr(self.d_kps), _L.ptr(self.d_cnt), self.cap, _L.ptr(d_pairs), B,
+                                                                  _L.ptr(self.bow["fv_nodes"]), _L.ptr(self.bow["fv_off"]), _L.ptr(self.bow["fv_feat"]),
+                                                                  _L.ptr(self.bow["n_nodes"]), 50, 0, 0.7, 1, _L.ptr(self.d_match), _L.ptr(self.d_nm), self.stream)
+                        assert rc == 0
+                    else:
+                        self.mt.match_pairs_device(self.d_desc, self.d_kps, self.d_cnt, self.cap, d_pairs, B, self.d_match, self.d_nm, stream=self.stream)
                     if timed:
                         e1.record()
                         self.match_ev.append((e0, e1))
@@ -202,6 +232,9 @@ def main():
     stage = {k: float(np.mean([st[k] for st in stages])) for k in stages[0]}
     mev = [a.elapsed_time(b) for ln in lanes for a, b in ln.match_ev]
     stage["match"] = float(np.mean(mev)) if mev else 0.0
+    bev = [a.elapsed_time(b) for ln in lanes for a, b in ln.bow_ev]
+    if bev:
+        stage["bow_transform"] = float(np.mean(bev))
     for ln in lanes:
         ln.ex.set_profiling(False)
     if world > 1:
@@ -251,7 +284,7 @@ def main():
             "dtype": "u8",
             "data": "synthetic",
             "config": {
-                "workload": args.workload + ("" if not args.no_match else " [extract only]"),
+                "workload": args.workload + ("" if not args.no_match else " [extract only]") + (" [+ BoW transform, SearchByBoW over FeatureVector groups]" if voc is not None else ""),
                 "frames_per_step_per_gpu": B,
                 "chunks_in_flight": len(lanes),
                 "rows": rows,

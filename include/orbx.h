@@ -153,6 +153,15 @@ int orbm_match_pairs_device(orbm_t* h, const uint8_t* d_desc, const orbx_keypoin
                             const int* d_pairs, int npairs, int th, int strict_lt, float ratio, int check_ori, int* d_match_t_of_q,
                             int* d_nmatches, void* stream);
 
+/* SearchByBoW proper for the pairs of an extraction batch: as orbm_match_pairs_device, but every query feature only meets
+ * the train features under the same vocabulary node, the groups and the query order (node ascending, feature ascending -- the
+ * merge walk of src/ORBmatcher.cc:256-268) being taken from the FeatureVectors orbv_transform_batch_device wrote for the batch
+ * (d_fv_nodes / d_fv_off / d_fv_feat / d_n_nodes, same cap).  Features of stopped words take no part, as in the reference.
+ * Enqueue only. */
+int orbm_match_pairs_bow_device(orbm_t* h, const uint8_t* d_desc, const orbx_keypoint_t* d_kps, const int* d_counts, int cap, const int* d_pairs,
+                                int npairs, const uint32_t* d_fv_nodes, const int* d_fv_off, const uint32_t* d_fv_feat, const int* d_n_nodes,
+                                int th, int strict_lt, float ratio, int check_ori, int* d_match_t_of_q, int* d_nmatches, void* stream);
+
 /* Tuning hook for orbm_match_pairs_device: enable = 1 arms the counters {speculative rounds, exact rescans,
  * 64-query chunks}; enable = 0 synchronises the device and copies them to out[3]. */
 int orbm_debug_counters(orbm_t* h, int enable, int* out);

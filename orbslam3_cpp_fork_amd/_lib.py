@@ -53,6 +53,7 @@ SIGNATURES = {
     "orbm_match_groups": (_i, [_vp, _vp, _i, _vp, _i, _i] + [_vp] * 8 + [_i, _i, _f, _i, _vp, _vp]),
     "orbm_match_bruteforce_device": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp, _vp, _vp]),
     "orbm_match_pairs_device": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _f, _i, _vp, _vp, _vp]),
+    "orbm_match_pairs_bow_device": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _vp, _vp, _vp]),
     "orbm_debug_counters": (_i, [_vp, _i, _vp]),
     "orbm_match_window": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _f, _f, _f, _f, _i, _i, _f, _i, _vp]),
     "orbm_search_by_projection": (_i, [_vp] * 7 + [_i] + [_vp] * 4 + [_i, _vp, _i, _f, _i, _f, _f, _f, _f, _f, _i, _i, _vp, _vp]),

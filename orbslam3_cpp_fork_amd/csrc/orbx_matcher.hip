@@ -171,6 +171,11 @@ struct GroupArgs {
   const int* pairs;
   const int* counts;  // [frames][2]: n, monoIndex
   int        cap;
+  const int* t_hi;    // optional end of every group's candidate range (else t_off[g + 1])
+  // batch form fed by orbv_transform_batch_device (FeatureVectors of the frames, [frames][cap (+1)]): the query order and the
+  // groups of pair p come from frame fq's FeatureVector, the candidates of group g from frame ft's range grpLo/grpHi[p][g]
+  const uint32_t* fvFeat;
+  const int *     fvOff, *fvNNodes, *grpLo, *grpHi;
   int*       dbg;  // optional tuning counters: [0] speculative rounds, [1] exact rescans, [2] 64-query chunks
 };
 
@@ -191,8 +196,19 @@ __device__ __forceinline__ GroupArgs pair_view(const GroupArgs& a, int p) {
   v.match_t_of_q = a.match_t_of_q + (size_t)p * a.cap;
   v.match_q_of_t = a.match_q_of_t + (size_t)p * a.cap;
   v.nmatches     = a.nmatches + p;
+  if (a.fvFeat) {  // SearchByBoW proper: merge walk of the two FeatureVectors (src/ORBmatcher.cc:256-268)
+    v.q_idx   = reinterpret_cast<const int*>(a.fvFeat + (size_t)fq * a.cap);
+    v.q_off   = a.fvOff + (size_t)fq * (a.cap + 1);
+    v.ngroups = a.fvNNodes[fq];
+    v.nqe     = v.q_off[v.ngroups];
+    v.t_idx   = reinterpret_cast<const int*>(a.fvFeat + (size_t)ft * a.cap);
+    v.t_off   = a.grpLo + (size_t)p * a.cap;
+    v.t_hi    = a.grpHi + (size_t)p * a.cap;
+  }
   return v;
 }
+
+__device__ __forceinline__ int group_hi(const GroupArgs& a, int g) { return a.t_hi ? a.t_hi[g] : a.t_off[g + 1]; }
 
 __device__ __forceinline__ int group_of(const GroupArgs& a, int e) {
   int lo = 0, hi = a.ngroups - 1;
@@ -216,7 +232,7 @@ __global__ __launch_bounds__(256) void k_group_topk(GroupArgs a0) {
   int g = 0, lo = 0, hi = nt;
   if (a.q_idx) {
     g  = group_of(a, e);
-    lo = a.t_off[g], hi = a.t_off[g + 1];
+    lo = a.t_off[g], hi = group_hi(a, g);
   }
   const int rq = a.q_idx ? a.q_idx[e] : e;
   uint32_t  out[kTopK];
@@ -471,7 +487,7 @@ __global__ __launch_bounds__(kResolveThreads) void k_group_resolve(GroupArgs a0)
             int       lo = 0, hi = nt;
             if (a.q_idx) {
               const int g = group_of(a, ee);
-              lo = a.t_off[g], hi = a.t_off[g + 1];
+              lo = a.t_off[g], hi = group_hi(a, g);
             }
             const int*      t_idx   = a.t_idx;
             const uint8_t*  t_valid = a.t_valid;
@@ -1223,10 +1239,35 @@ void orbm_three_maxima(const int* counts, int len, int* ind1, int* ind2, int* in
   *ind1 = i1, *ind2 = i2, *ind3 = i3;
 }
 
+
+// For pair p and every node g of the query frame's FeatureVector: the range of the train frame's FeatureVector payload that
+// belongs to the same node (empty if the train frame has no feature under it) -- the merge walk of SearchByBoW as a lookup.
+__global__ __launch_bounds__(256) void k_bow_pair_groups(const int* __restrict__ pairs, int cap, const uint32_t* __restrict__ fvNodes,
+                                                         const int* __restrict__ fvOff, const int* __restrict__ fvNNodes, int* __restrict__ grpLo,
+                                                         int* __restrict__ grpHi) {
+  const int p = blockIdx.y, g = blockIdx.x * 256 + threadIdx.x;
+  const int fq = pairs[2 * p], ft = pairs[2 * p + 1];
+  if (g >= fvNNodes[fq]) return;
+  const uint32_t  node = fvNodes[(size_t)fq * cap + g];
+  const uint32_t* tn   = fvNodes + (size_t)ft * cap;
+  int             lo = 0, hi = fvNNodes[ft];
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (tn[mid] < node)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  int a = 0, b = 0;
+  if (lo < fvNNodes[ft] && tn[lo] == node) a = fvOff[(size_t)ft * (cap + 1) + lo], b = fvOff[(size_t)ft * (cap + 1) + lo + 1];
+  grpLo[(size_t)p * cap + g] = a;
+  grpHi[(size_t)p * cap + g] = b;
+}
+
 static int launch_groups(orbm_matcher* h, GroupArgs& a, int nq_cap, hipStream_t s, int npairs = 1) {
   const int nqe = a.q_idx ? a.nqe : nq_cap;
   if (nqe > 0) {
-    if (a.q_idx)
+    if (a.q_idx || a.fvFeat)
       hipLaunchKernelGGL(k_group_topk, dim3((nqe + 3) / 4, npairs), dim3(256), 0, s, a);
     else if (a.t_valid)
       hipLaunchKernelGGL(k_bf_topk<true>, dim3((nqe + 255) / 256, npairs), dim3(256), 0, s, a);
@@ -1374,6 +1415,41 @@ int orbm_match_pairs_device(orbm_t* h, const uint8_t* d_desc, const orbx_keypoin
   a.pairs = d_pairs, a.counts = d_counts, a.cap = cap;
   if (h->dbgOn && !h->dbg.ensure(4)) a.dbg = h->dbg.p;
   return launch_groups(h, a, cap, stream ? (hipStream_t)stream : h->stream, npairs);
+}
+
+// SearchByBoW(KeyFrame*, Frame&, ...) proper for the frame pairs of an extraction batch: groups from the FeatureVectors that
+// orbv_transform_batch_device produced (see include/orbx.h).  Enqueue only.
+int orbm_match_pairs_bow_device(orbm_t* h, const uint8_t* d_desc, const orbx_keypoint_t* d_kps, const int* d_counts, int cap, const int* d_pairs,
+                                int npairs, const uint32_t* d_fv_nodes, const int* d_fv_off, const uint32_t* d_fv_feat, const int* d_n_nodes,
+                                int th, int strict_lt, float ratio, int check_ori, int* d_match_t_of_q, int* d_nmatches, void* stream) {
+  if (!h || !d_desc || !d_counts || !d_pairs || !d_fv_nodes || !d_fv_off || !d_fv_feat || !d_n_nodes || !d_match_t_of_q || !d_nmatches ||
+      cap <= 0 || npairs < 0 || cap > kMaxTrain) {
+    set_err("orbm_match_pairs_bow_device: bad arguments");
+    return -2;
+  }
+  if (check_ori && !d_kps) {
+    set_err("orbm_match_pairs_bow_device: check_ori needs the keypoint array");
+    return -2;
+  }
+  if (npairs == 0) return 0;
+  HIP_TRYM(hipSetDevice(h->device));
+  hipStream_t  s  = stream ? (hipStream_t)stream : h->stream;
+  const size_t np = (size_t)npairs * cap;
+  if (h->topk.ensure(np * kTopK) || h->nvalid.ensure(np) || h->binOf.ensure(np) || h->mt.ensure(np) || h->toff.ensure(np) || h->tidx.ensure(np))
+    return -3;
+  hipLaunchKernelGGL(k_bow_pair_groups, dim3((cap + 255) / 256, npairs), dim3(256), 0, s, d_pairs, cap, d_fv_nodes, d_fv_off, d_n_nodes, h->toff.p,
+                     h->tidx.p);
+  GroupArgs a;
+  memset(&a, 0, sizeof(a));
+  a.q = d_desc, a.t = d_desc, a.nq = cap, a.nt = cap, a.ngroups = 1, a.nqe = cap;
+  a.q_angle = d_kps ? &d_kps->angle : nullptr, a.t_angle = a.q_angle;
+  a.q_astride = a.t_astride = sizeof(orbx_keypoint_t) / 4;
+  a.th = th, a.strict_lt = strict_lt, a.check_ori = check_ori, a.ratio = ratio, a.dstar = prune_bound(th, ratio);
+  a.topk = h->topk.p, a.nvalid = h->nvalid.p, a.binOf = h->binOf.p;
+  a.match_t_of_q = d_match_t_of_q, a.match_q_of_t = h->mt.p, a.nmatches = d_nmatches;
+  a.pairs = d_pairs, a.counts = d_counts, a.cap = cap;
+  a.fvFeat = d_fv_feat, a.fvOff = d_fv_off, a.fvNNodes = d_n_nodes, a.grpLo = h->toff.p, a.grpHi = h->tidx.p;
+  return launch_groups(h, a, cap, s, npairs);
 }
 
 int orbm_match_window(orbm_t* h, const uint8_t* d1, const orbx_keypoint_t* kp1, int n1, const uint8_t* d2, const orbx_keypoint_t* kp2,

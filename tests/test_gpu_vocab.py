@@ -128,3 +128,19 @@ def test_extract_transform_search_by_bow(oracle):
         n_ref, mq, mt = oracle.match_groups(D[f - 1, :n0], D[f, :n1], a0, a1, 50, 0.7, False, True, flatten_feature_vectors(fvs[f - 1], fvs[f]))
         assert n_gpu == n_ref and match.tolist() == mt.tolist()
         assert n_gpu > 20
+    # the same, device-resident for all pairs at once: groups straight from the transform's FeatureVectors
+    from orbslam3_cpp_fork_amd import _lib
+
+    pairs = torch.from_numpy(np.stack([np.arange(B - 1), np.arange(1, B)], 1).astype(np.int32)).to(dev)
+    mtq = torch.zeros((B - 1, cap), dtype=torch.int32, device=dev)
+    nmm = torch.zeros(B - 1, dtype=torch.int32, device=dev)
+    rc = _lib.lib().orbm_match_pairs_bow_device(m._h, _lib.ptr(desc), _lib.ptr(kps), _lib.ptr(cnt), cap, _lib.ptr(pairs), B - 1, _lib.ptr(out["fv_nodes"]),
+                                                _lib.ptr(out["fv_off"]), _lib.ptr(out["fv_feat"]), _lib.ptr(out["n_nodes"]), 50, 0, 0.7, 1, _lib.ptr(mtq), _lib.ptr(nmm),
+                                                st.cuda_stream)
+    assert rc == 0
+    st.synchronize()
+    torch.cuda.synchronize()
+    for f in range(1, B):
+        n0, n1 = int(c[f - 1, 0]), int(c[f, 0])
+        n_ref, mq, mt = oracle.match_groups(D[f - 1, :n0], D[f, :n1], K[f - 1, :n0, 3], K[f, :n1, 3], 50, 0.7, False, True, flatten_feature_vectors(fvs[f - 1], fvs[f]))
+        assert int(nmm[f - 1]) == n_ref and mtq[f - 1, :n0].cpu().numpy().tolist() == mq.tolist()
