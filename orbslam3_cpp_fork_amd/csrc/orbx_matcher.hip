@@ -278,10 +278,14 @@ __device__ __forceinline__ int popc_acc(uint32_t x, int acc) {
   return r;
 }
 
+constexpr int kBfQueue     = 16;  // hits a lane may park between two merges
+constexpr int kBfFlushRows = 64;  // rows between two scheduled merges (power of two, multiple of 4)
+
 template <bool TVALID>
 __global__ __launch_bounds__(256) void k_bf_topk(GroupArgs a0) {
   __shared__ __align__(16) uint4 tile[2][kBfTile][2];  // double-buffered train descriptors
   __shared__ uint8_t             tval[2][TVALID ? kBfTile : 1];
+  __shared__ uint32_t            hitq[kBfQueue][256];  // parked hits, slot-major (conflict-free)
   const GroupArgs a   = pair_view(a0, blockIdx.y);
   const int       tid = threadIdx.x;
   const int       nq  = a.d_nq ? *a.d_nq : a.nq;
@@ -297,8 +301,24 @@ __global__ __launch_bounds__(256) void k_bf_topk(GroupArgs a0) {
   uint32_t k[kTopK];
 #pragma unroll
   for (int j = 0; j < kTopK; j++) k[j] = kEmpty;
-  int       cnt   = 0;
+  int       cnt = 0, qn = 0;
   const int dstar = a.dstar;
+  // A hit (distance under the pruning bound) is rare per LANE (a few dozen per query) but some lane of the wave hits in most
+  // rows, so merging every hit into the sorted list on the spot makes the whole wave execute the 8-deep insertion for
+  // ~3/4 of all rows.  Hits are parked in LDS instead (4 instructions) and all lanes merge theirs together every
+  // kBfFlushRows rows -- the loop runs for the busiest lane's count -- or earlier when a lane's slots run low.
+  auto flush = [&]() {
+    for (int i = 0; __ballot(i < qn) != 0ull; i++) {
+      uint32_t key = i < qn ? hitq[i][tid] : kEmpty;  // kEmpty falls through the network without touching the list
+#pragma unroll
+      for (int j = 0; j < kTopK; j++) {
+        const uint32_t lo = min(key, k[j]);
+        key               = max(key, k[j]);
+        k[j]              = lo;
+      }
+    }
+    qn = 0;
+  };
   // stage tile 0
   auto stage = [&](int buf, int base) {
     const int row = base + tid;
@@ -324,15 +344,8 @@ __global__ __launch_bounds__(256) void k_bf_topk(GroupArgs a0) {
     auto consider = [&](int r, int d) {
       if (d < dstar && active && (!TVALID || tval[buf][r])) {
         cnt++;
-        uint32_t key = ((uint32_t)d << kPosBits) | (uint32_t)(base + r);
-#pragma unroll
-        for (int j = 0; j < kTopK; j++) {
-          if (key < k[j]) {
-            const uint32_t t = k[j];
-            k[j]             = key;
-            key              = t;
-          }
-        }
+        hitq[qn][tid] = ((uint32_t)d << kPosBits) | (uint32_t)(base + r);
+        qn++;
       }
     };
     // four rows per step: eight LDS reads and 64 xor/popcount in one straight block, one pruning test for all four
@@ -344,9 +357,15 @@ __global__ __launch_bounds__(256) void k_bf_topk(GroupArgs a0) {
         consider(r + 1, d1);
         consider(r + 2, d2);
         consider(r + 3, d3);
+        if (__ballot(qn > kBfQueue - 4) != 0ull) flush();  // some lane could overflow in the next step
       }
+      if ((r & (kBfFlushRows - 1)) == kBfFlushRows - 4) flush();
     }
-    for (; r < n; r++) consider(r, dist(r));
+    for (; r < n; r++) {
+      consider(r, dist(r));
+      if (__ballot(qn > kBfQueue - 4) != 0ull) flush();
+    }
+    flush();
     __syncthreads();
     buf ^= 1;
   }
