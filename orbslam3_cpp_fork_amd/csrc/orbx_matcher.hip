@@ -279,7 +279,7 @@ __device__ __forceinline__ int popc_acc(uint32_t x, int acc) {
 }
 
 constexpr int kBfQueue     = 16;  // hits a lane may park between two merges
-constexpr int kBfFlushRows = 64;  // rows between two scheduled merges (power of two, multiple of 4)
+constexpr int kBfFlushRows = 32;  // rows between two scheduled merges (power of two, multiple of 4)
 
 template <bool TVALID>
 __global__ __launch_bounds__(256) void k_bf_topk(GroupArgs a0) {
