@@ -110,6 +110,27 @@ class ORBmatcher {
     return n;
   }
 
+  // Array core of SearchByProjection(Frame& F, const std::vector<MapPoint*>& vpMapPoints, th, bFarPoints, thFarPoints)
+  // (src/ORBmatcher.cc:38-227, Nleft == -1).  Per MapPoint: mpValid = mbTrackInView && !isBad() && !(bFarPoints && mTrackDepth >
+  // thFarPoints); mpUV = (mTrackProjX, mTrackProjY); mpProjXR = mTrackProjXR (read only with curURight); mpLevel = mnTrackScaleLevel;
+  // mpRadius = RadiusByViewingCos(mTrackViewCos) (* th when th != 1).  curOfMp[i] = the feature that receives MapPoint i.
+  int SearchByProjectionMapPointsArrays(const orbx_cv::Mat& mpDesc, const std::vector<orbx_cv::Point2f>& mpUV, const std::vector<float>& mpProjXR,
+                                        const std::vector<int>& mpLevel, const std::vector<float>& mpRadius, const std::vector<unsigned char>& mpValid,
+                                        const orbx_cv::Mat& curDesc, const std::vector<orbx_cv::KeyPoint>& curKeysUn, const std::vector<float>* curURight,
+                                        const std::vector<unsigned char>* curOccupied, const std::vector<float>& scaleFactors, const float bounds[4],
+                                        std::vector<int>& curOfMp) {
+    const int n1 = (int)mpLevel.size(), n2 = (int)curKeysUn.size();
+    curOfMp.assign(n1, -1);
+    std::vector<uint8_t> d1 = pack(mpDesc), d2 = pack(curDesc);
+    int n = orbm_search_by_projection_map(h_, d1.data(), reinterpret_cast<const float*>(mpUV.data()), mpProjXR.empty() ? nullptr : mpProjXR.data(),
+                                          mpLevel.data(), mpRadius.data(), mpValid.empty() ? nullptr : mpValid.data(), n1, d2.data(),
+                                          reinterpret_cast<const orbx_keypoint_t*>(curKeysUn.data()), curURight ? curURight->data() : nullptr,
+                                          curOccupied ? curOccupied->data() : nullptr, n2, scaleFactors.data(), (int)scaleFactors.size(), mfNNratio,
+                                          bounds[0], bounds[1], bounds[2], bounds[3], TH_HIGH, curOfMp.data(), nullptr);
+    if (n <= -2) throw std::runtime_error(std::string("orbm_search_by_projection_map: ") + orbx_last_error());
+    return n;
+  }
+
   orbm_t* handle() { return h_; }
 
  protected:

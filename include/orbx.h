@@ -199,6 +199,19 @@ int orbx_undistort_keypoints_device(orbx_t* h, const orbx_keypoint_t* d_kps, con
 /* Frame::ComputeImageBounds (src/Frame.cc:915-943): out = {mnMinX, mnMaxX, mnMinY, mnMaxY}; host arithmetic, same core. */
 int orbx_image_bounds(int cols, int rows, const float K[4], const float* dist, int ndist, float out[4]);
 
+/* ORBmatcher::SearchByProjection(Frame& F, const std::vector<MapPoint*>& vpMapPoints, th, bFarPoints, thFarPoints)
+ * (src/ORBmatcher.cc:38-227, F.Nleft == -1) -- the local-map tracking search.  mp_valid[i] = mbTrackInView && !isBad() &&
+ * !(bFarPoints && mTrackDepth > thFarPoints); mp_uv = (mTrackProjX, mTrackProjY); mp_proj_xr = mTrackProjXR (only read with
+ * cur_u_right); mp_level = mnTrackScaleLevel; mp_radius = RadiusByViewingCos(mTrackViewCos) (* th when th != 1).  Window
+ * mp_radius * scale[level] over levels [level - 1, level]; best and second-best unclaimed candidate; accepted when
+ * best <= th_dist (TH_HIGH) unless both sit on one pyramid level and best > ratio * second (:137-142).  Same conventions for
+ * cur_* and the outputs as orbm_search_by_projection.  Host pointers, synchronous. */
+int orbm_search_by_projection_map(orbm_t* h, const uint8_t* mp_desc, const float* mp_uv, const float* mp_proj_xr, const int* mp_level,
+                                  const float* mp_radius, const uint8_t* mp_valid, int n1, const uint8_t* cur_desc,
+                                  const orbx_keypoint_t* cur_kp, const float* cur_u_right, const uint8_t* cur_occupied, int n2,
+                                  const float* scale_factors, int nlevels, float ratio, float min_x, float max_x, float min_y, float max_y,
+                                  int th_dist, int* cur_of_mp, int* mp_of_cur);
+
 /* Frame::AssignFeaturesToGrid (src/Frame.cc:524-553) for every frame of an extraction batch, on the device: the (undistorted)
  * keypoints that fall inside the 64 x 48 grid over [min_x, max_x] x [min_y, max_y], in the scan order of GetFeaturesInArea
  * (cells (ix, iy) ascending, feature index ascending inside a cell).  Frame f writes d_g_idx / d_g_cx / d_g_cy at [f * cap ..]

@@ -299,6 +299,26 @@ def search_by_projection(last_desc, last_uv, last_invz, last_octave, last_angle,
     return n, col, loc
 
 
+def search_by_projection_map(mp_desc, mp_uv, mp_proj_xr, mp_level, mp_radius, mp_valid, cur_desc, cur_kp, cur_u_right, cur_occupied, scale_factors, ratio, bounds, th_dist=100):
+    """ORBmatcher::SearchByProjection(Frame&, vector<MapPoint*>&, th, ...) at array level (see orb_oracle.h)."""
+    mp_desc = np.ascontiguousarray(mp_desc, np.uint8)
+    cur_desc = np.ascontiguousarray(cur_desc, np.uint8)
+    cur_kp = np.ascontiguousarray(cur_kp, KP_DTYPE)
+    n1, n2 = len(mp_desc), len(cur_desc)
+    uv = np.ascontiguousarray(mp_uv, np.float32).reshape(-1, 2)
+    xr = _opt(mp_proj_xr, np.float32)
+    lv = np.ascontiguousarray(mp_level, np.int32)
+    rad = np.ascontiguousarray(mp_radius, np.float32)
+    va, ur, occ = _opt(mp_valid, np.uint8), _opt(cur_u_right, np.float32), _opt(cur_occupied, np.uint8)
+    sf = np.ascontiguousarray(scale_factors, np.float32)
+    com, moc = np.zeros(n1, np.int32), np.zeros(n2, np.int32)
+    L = lib()
+    L.orao_search_by_projection_map.argtypes = [C.c_void_p] * 6 + [C.c_int] + [C.c_void_p] * 4 + [C.c_int, C.c_void_p] + [C.c_float] * 5 + [C.c_int, C.c_void_p, C.c_void_p]
+    n = L.orao_search_by_projection_map(_p(mp_desc), _p(uv), _p(xr), _p(lv), _p(rad), _p(va), n1, _p(cur_desc), _p(cur_kp), _p(ur), _p(occ), n2, _p(sf), float(ratio),
+                                        *[float(b) for b in bounds], int(th_dist), _p(com), _p(moc))
+    return n, com, moc
+
+
 def undistort_keypoints(kps, K, dist):
     """Frame::UndistortKeyPoints: K = (fx, fy, cx, cy), dist = (k1, k2, p1, p2[, k3])."""
     kps = np.ascontiguousarray(kps, KP_DTYPE)

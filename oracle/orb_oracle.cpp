@@ -1173,6 +1173,90 @@ int orao_match_window(const uint8_t* d1, const orao_keypoint_t* kp1, int n1, con
 }
 
 
+// SearchByProjection(Frame& F, const std::vector<MapPoint*>& vpMapPoints, th, bFarPoints, thFarPoints) (src/ORBmatcher.cc:38-227), Nleft == -1
+int orao_search_by_projection_map(const uint8_t* mp_desc, const float* mp_uv, const float* mp_proj_xr, const int* mp_level,
+                                  const float* mp_radius, const uint8_t* mp_valid, int n1, const uint8_t* cur_desc,
+                                  const orao_keypoint_t* cur_kp, const float* cur_u_right, const uint8_t* cur_occupied, int n2,
+                                  const float* mvScaleFactors, float mfNNratio, float mnMinX, float mnMaxX, float mnMinY, float mnMaxY,
+                                  int th_dist, int* cur_of_mp, int* mp_of_cur) {
+  const int   GRID_COLS = 64, GRID_ROWS = 48;
+  const float gwInv = static_cast<float>(GRID_COLS) / (mnMaxX - mnMinX);
+  const float ghInv = static_cast<float>(GRID_ROWS) / (mnMaxY - mnMinY);
+  std::vector<std::vector<int>> grid((size_t)GRID_COLS * GRID_ROWS);
+  for (int i = 0; i < n2; i++) {
+    int posX = (int)std::round((cur_kp[i].x - mnMinX) * gwInv);
+    int posY = (int)std::round((cur_kp[i].y - mnMinY) * ghInv);
+    if (posX < 0 || posX >= GRID_COLS || posY < 0 || posY >= GRID_ROWS) continue;
+    grid[(size_t)posX * GRID_ROWS + posY].push_back(i);
+  }
+  std::vector<int> mvpMapPoints(n2, -1), curOfMp(n1, -1);
+  int              nmatches = 0;
+  std::vector<int> vIndices;
+  for (int iMP = 0; iMP < n1; iMP++) {
+    if (mp_valid && !mp_valid[iMP]) continue;  // :50-62
+    const int   nPredictedLevel = mp_level[iMP];
+    const float r               = mp_radius[iMP];  // RadiusByViewingCos(...) (* th) (:67-71)
+    // F.GetFeaturesInArea(mTrackProjX, mTrackProjY, r * mvScaleFactors[level], level - 1, level)
+    vIndices.clear();
+    {
+      const float x = mp_uv[2 * iMP], y = mp_uv[2 * iMP + 1], rr = r * mvScaleFactors[nPredictedLevel];
+      const int   minLevel = nPredictedLevel - 1, maxLevel = nPredictedLevel;
+      const int   nMinCellX = std::max(0, (int)std::floor((x - mnMinX - rr) * gwInv));
+      const int   nMaxCellX = std::min(GRID_COLS - 1, (int)std::ceil((x - mnMinX + rr) * gwInv));
+      const int   nMinCellY = std::max(0, (int)std::floor((y - mnMinY - rr) * ghInv));
+      const int   nMaxCellY = std::min(GRID_ROWS - 1, (int)std::ceil((y - mnMinY + rr) * ghInv));
+      if (!(nMinCellX >= GRID_COLS || nMaxCellX < 0 || nMinCellY >= GRID_ROWS || nMaxCellY < 0)) {
+        const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+        for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
+          for (int iy = nMinCellY; iy <= nMaxCellY; iy++) {
+            const std::vector<int>& vCell = grid[(size_t)ix * GRID_ROWS + iy];
+            for (size_t j = 0; j < vCell.size(); j++) {
+              const orao_keypoint_t& kpUn = cur_kp[vCell[j]];
+              if (bCheckLevels) {
+                if (kpUn.octave < minLevel) continue;
+                if (maxLevel >= 0 && kpUn.octave > maxLevel) continue;
+              }
+              const float distx = kpUn.x - x, disty = kpUn.y - y;
+              if (std::fabs(distx) < rr && std::fabs(disty) < rr) vIndices.push_back(vCell[j]);
+            }
+          }
+      }
+    }
+    if (vIndices.empty()) continue;
+    const uint8_t* MPdescriptor = mp_desc + (size_t)iMP * 32;
+    int            bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+    for (int idx : vIndices) {
+      if (mvpMapPoints[idx] >= 0 || (cur_occupied && cur_occupied[idx])) continue;  // :92-96
+      if (cur_u_right && cur_u_right[idx] > 0) {                                       // :98-103
+        const float er = std::fabs(mp_proj_xr[iMP] - cur_u_right[idx]);
+        if (er > r * mvScaleFactors[nPredictedLevel]) continue;
+      }
+      const int dist = orao_hamming(MPdescriptor, cur_desc + (size_t)idx * 32);
+      if (dist < bestDist) {
+        bestDist2  = bestDist;
+        bestDist   = dist;
+        bestLevel2 = bestLevel;
+        bestLevel  = cur_kp[idx].octave;
+        bestIdx    = idx;
+      } else if (dist < bestDist2) {
+        bestLevel2 = cur_kp[idx].octave;
+        bestDist2  = dist;
+      }
+    }
+    if (bestDist <= th_dist) {  // TH_HIGH (:137)
+      if (bestLevel == bestLevel2 && bestDist > mfNNratio * bestDist2) continue;
+      if (bestLevel != bestLevel2 || bestDist <= mfNNratio * bestDist2) {
+        mvpMapPoints[bestIdx] = iMP;
+        curOfMp[iMP]          = bestIdx;
+        nmatches++;
+      }
+    }
+  }
+  if (cur_of_mp) memcpy(cur_of_mp, curOfMp.data(), sizeof(int) * n1);
+  if (mp_of_cur) memcpy(mp_of_cur, mvpMapPoints.data(), sizeof(int) * n2);
+  return nmatches;
+}
+
 // cv::undistortPoints for one CV_32FC2 point (OpenCV >= 4.5 undistort.dispatch.cpp, cvUndistortPointsInternal), criteria =
 // TermCriteria(MAX_ITER, 5, 0.01), R empty, P = the 3x3 new camera matrix.
 static void cv_undistort_point(const double A[3][3], const double k[14], const double PP[3][3], float sx, float sy, float* dx, float* dy) {

@@ -123,6 +123,17 @@ int orao_search_by_projection(const uint8_t* last_desc, const float* last_uv, co
                               const float* scale_factors, float th, int dir, float mbf, float min_x, float max_x, float min_y,
                               float max_y, int th_dist, int check_ori, int* cur_of_last, int* last_of_cur);
 
+/* ORBmatcher::SearchByProjection(Frame& F, const std::vector<MapPoint*>& vpMapPoints, th, bFarPoints, thFarPoints)
+ * (src/ORBmatcher.cc:38-227, F.Nleft == -1) at array level.  mp_valid[i] = mbTrackInView && !isBad() && !(far) (:50-62);
+ * mp_uv = (mTrackProjX, mTrackProjY), mp_proj_xr = mTrackProjXR (needed only with cur_u_right), mp_level = mnTrackScaleLevel,
+ * mp_radius = RadiusByViewingCos(mTrackViewCos) [* th if th != 1] (:67-71).  Best and second-best candidate, TH_HIGH, and the
+ * ratio veto only when both sit on the same pyramid level (:137-142).  Matched features are closed to later points. */
+int orao_search_by_projection_map(const uint8_t* mp_desc, const float* mp_uv, const float* mp_proj_xr, const int* mp_level,
+                                  const float* mp_radius, const uint8_t* mp_valid, int n1, const uint8_t* cur_desc,
+                                  const orao_keypoint_t* cur_kp, const float* cur_u_right, const uint8_t* cur_occupied, int n2,
+                                  const float* scale_factors, float ratio, float min_x, float max_x, float min_y, float max_y, int th_dist,
+                                  int* cur_of_mp, int* mp_of_cur);
+
 /* Frame::UndistortKeyPoints (src/Frame.cc:886-913): cv::undistortPoints(mat, mat, K, mDistCoef, cv::Mat(), mK) on the keypoint
  * coordinates (OpenCV cvUndistortPointsInternal, 5 iterations, doubles); K = (fx, fy, cx, cy) floats, dist = k1 k2 p1 p2 [k3]
  * floats (ndist = 4 or 5).  dist[0] == 0 copies the keypoints (:887-890).  The other KeyPoint fields are copied. */

@@ -832,6 +832,12 @@ struct ProjArgs {
   const int*             ngOf;
   const orbx_keypoint_t* kp1;  // last frame's keypoints: octave and angle are read from here when set
   int                    cap, hasLastDesc;
+  // mode 1 = SearchByProjection(Frame&, vector<MapPoint*>&, th, ...) (src/ORBmatcher.cc:38-227): radius1[i] = RadiusByViewingCos * th,
+  // levels [predicted - 1, predicted], `invz` carries mTrackProjXR, best / second-best with the same-level ratio rule
+  int          mode;
+  const float* radius1;
+  float        ratio;
+  int          dstar;  // mode 1: a second-best at distance >= dstar can never veto a best <= thDist
 };
 
 __device__ __forceinline__ ProjArgs proj_view(const ProjArgs& a, int p) {
@@ -867,7 +873,10 @@ __device__ __forceinline__ ProjQuery proj_query(const ProjArgs& a, int i) {
   q.invz      = a.invz ? a.invz[i] : 0.f;
   const int o = a.kp1 ? a.kp1[i].octave : a.oct1[i];
   q.r         = a.th * a.sf[o];  // :1736
-  if (a.dir == 1)
+  if (a.mode == 1) {
+    q.r    = a.radius1[i] * a.sf[o];  // r * F.mvScaleFactors[nPredictedLevel] (:70-76)
+    q.minL = o - 1, q.maxL = o;
+  } else if (a.dir == 1)
     q.minL = o, q.maxL = -1;  // bForward: GetFeaturesInArea(u, v, radius, nLastOctave)
   else if (a.dir == 2)
     q.minL = 0, q.maxL = o;   // bBackward
@@ -895,8 +904,8 @@ __device__ __forceinline__ int proj_candidate(const ProjArgs& a, const ProjQuery
   }
   const float dx = kp.x - q.u, dy = kp.y - q.v;
   if (!(fabsf(dx) < q.r && fabsf(dy) < q.r)) return -1;
-  if (a.uRight && a.uRight[i2] > 0) {  // :1770-1776
-    const float ur = q.u - a.mbf * q.invz;
+  if (a.uRight && a.uRight[i2] > 0) {  // :1770-1776 / :101-106
+    const float ur = a.mode == 1 ? q.invz : q.u - a.mbf * q.invz;  // mode 1: pMP->mTrackProjXR
     const float er = fabsf(ur - a.uRight[i2]);
     if (er > q.r) return -1;
   }
@@ -917,7 +926,7 @@ __global__ __launch_bounds__(256) void k_proj_topk(ProjArgs a0) {
       const ProjArgs& ar = a;
       wave_topk(
           a.d1 + (size_t)i1 * 32, a.d2, 0, a.ng, [&ar, &q](int pos) { return proj_candidate(ar, q, pos); },
-          [thd = ar.thDist](int, int d) { return d <= thd; }, out, &nv);  // only "bestDist <= TH_HIGH" can match (:1788)
+          [thd = ar.mode == 1 ? ar.dstar - 1 : ar.thDist](int, int d) { return d <= thd; }, out, &nv);  // mode 0: only "bestDist <= TH_HIGH" can match (:1788)
     }
   }
   if ((threadIdx.x & 63) == 0) {
@@ -996,13 +1005,17 @@ __global__ __launch_bounds__(64) void k_proj_resolve(ProjArgs a0) {
   for (int c0 = 0; c0 < a.n1; c0 += 64) {
     const int i1 = c0 + lane;
     uint32_t  row[kTopK];  // feature index per list entry (kEmpty = none); the list is sorted by (distance, scan position)
-    int       len = 0, nv = 0;
+    uint32_t  dl[kTopK];   // mode 1: distance << 8 | level of that entry
+    int       len = 0, nv = 0, dK = 0;
 #pragma unroll
     for (int j = 0; j < kTopK; j++) {
-      row[j] = kEmpty;
+      row[j] = kEmpty, dl[j] = 0;
       if (i1 < a.n1) {
         const uint32_t key = a.topk[(size_t)i1 * kTopK + j];
-        if (key != kEmpty) row[j] = (uint32_t)a.g_idx[key & kPosMask], len = j + 1;
+        if (key != kEmpty) {
+          row[j] = (uint32_t)a.g_idx[key & kPosMask], len = j + 1, dK = (int)(key >> kPosBits);
+          if (a.mode == 1) dl[j] = ((key >> kPosBits) << 8) | (uint32_t)(a.kp2[row[j]].octave & 0xff);
+        }
       }
     }
     if (i1 < a.n1) nv = a.nvalid[i1];
@@ -1011,18 +1024,50 @@ __global__ __launch_bounds__(64) void k_proj_resolve(ProjArgs a0) {
     unsigned long long pending   = __ballot(len > 0);
     while (pending) {
       const bool act = (pending >> lane) & 1ull;
-      int        prop = -1;
-      bool       dry  = false;  // list exhausted
+      int        prop = -1, dep1 = -1, dep2 = -1;  // proposal; the best / second-best free features the decision depends on
+      bool       dry  = false;          // the list cannot decide this point
       if (act) {
+        int j1 = -1, j2 = -1;
 #pragma unroll
         for (int j = kTopK - 1; j >= 0; j--)
-          if (row[j] != kEmpty && !(claimed[row[j] >> 5] & (1u << (row[j] & 31)))) prop = (int)row[j];
-        dry = prop < 0;
+          if (row[j] != kEmpty && !(claimed[row[j] >> 5] & (1u << (row[j] & 31)))) j2 = j1, j1 = j;
+        uint32_t r1 = kEmpty, r2 = kEmpty, e1 = 0, e2 = 0;
+#pragma unroll
+        for (int j = 0; j < kTopK; j++) {
+          if (j == j1) r1 = row[j], e1 = dl[j];
+          if (j == j2) r2 = row[j], e2 = dl[j];
+        }
+        dep1 = j1 >= 0 ? (int)r1 : -1;
+        if (a.mode != 1) {
+          prop = dep1;
+          dry  = prop < 0;
+        } else if (j1 < 0) {
+          dry = true;  // nothing free in the list: decided "no match" unless the list is a truncated prefix
+        } else {
+          const int d1 = (int)(e1 >> 8), l1 = (int)(e1 & 0xff);
+          if (d1 <= a.thDist) {  // bestDist <= TH_HIGH (:137)
+            bool accept;
+            if (j2 >= 0) {
+              const int d2 = (int)(e2 >> 8), l2 = (int)(e2 & 0xff);
+              accept       = !(l1 == l2 && (float)d1 > a.ratio * (float)d2);  // :138-142
+              dep2         = (int)r2;
+            } else if (!truncated) {
+              accept = true;  // no second candidate: bestLevel2 == -1
+            } else {
+              // whatever comes after the list is at least dK away: it cannot veto if even dK does not
+              accept = !((float)d1 > a.ratio * (float)dK);
+              dry    = !accept;  // undecidable from the list -> exact rescan
+            }
+            if (accept) prop = (int)r1;
+          }
+        }
       }
       if (act && prop >= 0) atomicMin(&minLane[prop & (kProjTab - 1)], (uint32_t)lane);
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      // a lane is blocked by an earlier lane of this round hashing to the same slot (a false sharing only delays it)
-      const bool blocked = act && prop >= 0 && minLane[prop & (kProjTab - 1)] < (uint32_t)lane;
+      // a lane is blocked by an earlier lane of this round PROPOSING (hashing to the slot of) a feature its decision depends on:
+      // its best free candidate -- also when the lane itself vetoes it -- or, in mode 1, its runner-up; false sharing only delays
+      const bool blocked = act && ((dep1 >= 0 && minLane[dep1 & (kProjTab - 1)] < (uint32_t)lane) ||
+                                   (dep2 >= 0 && minLane[dep2 & (kProjTab - 1)] < (uint32_t)lane));
       const bool rescan  = act && dry && truncated;
       const unsigned long long stopMask = __ballot(blocked || rescan);
       const int                f        = stopMask ? __ffsll((long long)stopMask) - 1 : 64;
@@ -1048,8 +1093,17 @@ __global__ __launch_bounds__(64) void k_proj_resolve(ProjArgs a0) {
               const int i2 = proj_candidate(ar, q, pos);
               return (i2 >= 0 && (cl[i2 >> 5] & (1u << (i2 & 31)))) ? -1 : i2;
             },
-            [thd = ar.thDist](int, int d) { return d <= thd; }, out, &nv2);
-        if (out[0] != kEmpty) {
+            [thd = ar.mode == 1 ? ar.dstar - 1 : ar.thDist](int, int d) { return d <= thd; }, out, &nv2);
+        bool take = out[0] != kEmpty;
+        if (take && a.mode == 1) {
+          const int d1 = (int)(out[0] >> kPosBits), l1 = a.kp2[a.g_idx[out[0] & kPosMask]].octave;
+          take         = d1 <= a.thDist;
+          if (take && out[1] != kEmpty) {
+            const int d2 = (int)(out[1] >> kPosBits), l2 = a.kp2[a.g_idx[out[1] & kPosMask]].octave;
+            take         = !(l1 == l2 && (float)d1 > a.ratio * (float)d2);
+          }
+        }
+        if (take) {
           const int b = a.g_idx[out[0] & kPosMask];
           if (lane == f) {
             claimed[b >> 5] |= 1u << (b & 31);
@@ -1549,12 +1603,45 @@ int orbm_match_window(orbm_t* h, const uint8_t* d1, const orbx_keypoint_t* kp1, 
 }
 
 // ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, th, bMono) at array level (see include/orbx.h)
+static int proj_single(orbm_t* h, int mode, const float* radius1, float ratio, const uint8_t* last_desc, const float* last_uv, const float* last_invz,
+                       const int* last_octave, const float* last_angle, const uint8_t* last_valid, int n1, const uint8_t* cur_desc,
+                       const orbx_keypoint_t* cur_kp, const float* cur_u_right, const uint8_t* cur_occupied, int n2,
+                       const float* scale_factors, int nlevels, float th, int dir, float mbf, float min_x, float max_x, float min_y,
+                       float max_y, int th_dist, int check_ori, int* cur_of_last, int* last_of_cur);
+
 int orbm_search_by_projection(orbm_t* h, const uint8_t* last_desc, const float* last_uv, const float* last_invz, const int* last_octave,
                               const float* last_angle, const uint8_t* last_valid, int n1, const uint8_t* cur_desc,
                               const orbx_keypoint_t* cur_kp, const float* cur_u_right, const uint8_t* cur_occupied, int n2,
                               const float* scale_factors, int nlevels, float th, int dir, float mbf, float min_x, float max_x,
                               float min_y, float max_y, int th_dist, int check_ori, int* cur_of_last, int* last_of_cur) {
-  if (!h || n1 < 0 || n2 < 0 || !cur_of_last || (n1 > 0 && (!last_desc || !last_uv || !last_octave || !last_angle)) ||
+  if (n1 > 0 && !last_angle) {
+    set_err("orbm_search_by_projection: bad arguments");
+    return -2;
+  }
+  return proj_single(h, 0, nullptr, 0.f, last_desc, last_uv, last_invz, last_octave, last_angle, last_valid, n1, cur_desc, cur_kp, cur_u_right,
+                     cur_occupied, n2, scale_factors, nlevels, th, dir, mbf, min_x, max_x, min_y, max_y, th_dist, check_ori, cur_of_last, last_of_cur);
+}
+
+// SearchByProjection(Frame& F, const std::vector<MapPoint*>&, th, bFarPoints, thFarPoints) (src/ORBmatcher.cc:38-227) on arrays
+int orbm_search_by_projection_map(orbm_t* h, const uint8_t* mp_desc, const float* mp_uv, const float* mp_proj_xr, const int* mp_level,
+                                  const float* mp_radius, const uint8_t* mp_valid, int n1, const uint8_t* cur_desc,
+                                  const orbx_keypoint_t* cur_kp, const float* cur_u_right, const uint8_t* cur_occupied, int n2,
+                                  const float* scale_factors, int nlevels, float ratio, float min_x, float max_x, float min_y, float max_y,
+                                  int th_dist, int* cur_of_mp, int* mp_of_cur) {
+  if (n1 > 0 && !mp_radius) {
+    set_err("orbm_search_by_projection_map: bad arguments");
+    return -2;
+  }
+  return proj_single(h, 1, mp_radius, ratio, mp_desc, mp_uv, mp_proj_xr, mp_level, nullptr, mp_valid, n1, cur_desc, cur_kp, cur_u_right, cur_occupied,
+                     n2, scale_factors, nlevels, 1.0f, 0, 0.f, min_x, max_x, min_y, max_y, th_dist, 0, cur_of_mp, mp_of_cur);
+}
+
+static int proj_single(orbm_t* h, int mode, const float* radius1, float ratio, const uint8_t* last_desc, const float* last_uv, const float* last_invz,
+                       const int* last_octave, const float* last_angle, const uint8_t* last_valid, int n1, const uint8_t* cur_desc,
+                       const orbx_keypoint_t* cur_kp, const float* cur_u_right, const uint8_t* cur_occupied, int n2,
+                       const float* scale_factors, int nlevels, float th, int dir, float mbf, float min_x, float max_x, float min_y,
+                       float max_y, int th_dist, int check_ori, int* cur_of_last, int* last_of_cur) {
+  if (!h || n1 < 0 || n2 < 0 || !cur_of_last || (n1 > 0 && (!last_desc || !last_uv || !last_octave)) ||
       (n2 > 0 && (!cur_desc || !cur_kp)) || !scale_factors || nlevels < 1 || nlevels > 64 || dir < 0 || dir > 2 || !(max_x > min_x) ||
       !(max_y > min_y) || (cur_u_right && n1 > 0 && !last_invz)) {
     set_err("orbm_search_by_projection: bad arguments");
@@ -1597,7 +1684,7 @@ int orbm_search_by_projection(orbm_t* h, const uint8_t* last_desc, const float* 
       }
   }
   hipStream_t  s  = h->stream;
-  const size_t inBytes = (size_t)n1 * (32 + 8 + 4 + 4 + 4 + 1) + (size_t)n2 * (32 + sizeof(orbx_keypoint_t) + 4 + 1) + (size_t)ng * 6 + 64 * 4 + 16 * 16;
+  const size_t inBytes = (size_t)n1 * (32 + 8 + 4 + 4 + 4 + 4 + 1) + (size_t)n2 * (32 + sizeof(orbx_keypoint_t) + 4 + 1) + (size_t)ng * 6 + 64 * 4 + 16 * 16;
   const size_t outBytes = (size_t)(n1 + n2 + 4) * 4 + 64;
   if (h->in.reserve(inBytes) || h->out.reserve(outBytes) || h->topk.ensure((size_t)(n1 + 1) * kTopK) || h->nvalid.ensure(n1 + 1) ||
       h->binOf.ensure(n1 + 1))
@@ -1607,7 +1694,13 @@ int orbm_search_by_projection(orbm_t* h, const uint8_t* last_desc, const float* 
   Arena& in = h->in;
   a.d1 = in.put(last_desc, (size_t)n1 * 32), a.d2 = in.put(cur_desc, (size_t)n2 * 32), a.kp2 = in.put(cur_kp, n2);
   a.g_idx = in.put(gidx.data(), ng), a.g_cx = in.put(gcx.data(), ng), a.g_cy = in.put(gcy.data(), ng);
-  a.uv = in.put(last_uv, (size_t)2 * n1), a.angle1 = in.put(last_angle, n1), a.invz = last_invz ? in.put(last_invz, n1) : nullptr;
+  a.uv = in.put(last_uv, (size_t)2 * n1), a.angle1 = last_angle ? in.put(last_angle, n1) : nullptr, a.invz = last_invz ? in.put(last_invz, n1) : nullptr;
+  a.radius1 = radius1 ? in.put(radius1, n1) : nullptr, a.mode = mode, a.ratio = ratio;
+  if (mode == 1) {  // a runner-up at distance D vetoes a best d1 <= th only if d1 > ratio * D: none can from the first D with !(th > ratio * D)
+    int D = th_dist + 1;
+    while (D < 257 && (float)th_dist > ratio * (float)D) D++;
+    a.dstar = D;
+  }
   a.sf = in.put(scale_factors, nlevels), a.uRight = cur_u_right ? in.put(cur_u_right, n2) : nullptr, a.oct1 = in.put(last_octave, n1);
   a.valid1 = last_valid ? in.put(last_valid, n1) : nullptr, a.occupied = cur_occupied ? in.put(cur_occupied, n2) : nullptr;
   HIP_TRYM(hipMemcpyAsync(in.d, in.h, in.off, hipMemcpyHostToDevice, s));

@@ -145,6 +145,30 @@ class ORBmatcher:
         )
         return n, col, loc
 
+    def SearchByProjectionMapPoints(self, mp_desc, mp_uv, mp_level, mp_radius, cur_kps, cur_desc, scale_factors, bounds, mp_valid=None, mp_proj_xr=None,
+                                    cur_u_right=None, cur_occupied=None):
+        """SearchByProjection(Frame& F, const vector<MapPoint*>&, th, bFarPoints, thFarPoints) (src/ORBmatcher.cc:38-227, Nleft == -1) on arrays;
+        mp_radius = RadiusByViewingCos(viewCos) * th.  Returns (nmatches, cur_of_mp[n1], mp_of_cur[n2])."""
+        d1 = np.ascontiguousarray(mp_desc, np.uint8).reshape(-1, 32)
+        d2 = np.ascontiguousarray(cur_desc, np.uint8).reshape(-1, 32)
+        kp2 = np.ascontiguousarray(cur_kps, KP_DTYPE)
+        n1, n2 = len(d1), len(d2)
+        uv = np.ascontiguousarray(mp_uv, np.float32).reshape(-1, 2)
+        lv = np.ascontiguousarray(mp_level, np.int32)
+        rad = np.ascontiguousarray(mp_radius, np.float32)
+        sf = np.ascontiguousarray(scale_factors, np.float32)
+        opt = lambda a, dt: None if a is None else np.ascontiguousarray(a, dt)
+        va, xr, ur, occ = opt(mp_valid, np.uint8), opt(mp_proj_xr, np.float32), opt(cur_u_right, np.float32), opt(cur_occupied, np.uint8)
+        com, moc = np.zeros(n1, np.int32), np.zeros(n2, np.int32)
+        n = check(
+            _lib.lib().orbm_search_by_projection_map(
+                self._h, ptr(d1), ptr(uv), ptr(xr), ptr(lv), ptr(rad), ptr(va), n1, ptr(d2), ptr(kp2), ptr(ur), ptr(occ), n2, ptr(sf), len(sf), self.mfNNratio,
+                float(bounds[0]), float(bounds[1]), float(bounds[2]), float(bounds[3]), self.TH_HIGH, ptr(com), ptr(moc),
+            ),
+            "orbm_search_by_projection_map",
+        )
+        return n, com, moc
+
     def match_bruteforce_device(self, d_q, d_q_kp, d_nq, cap_q, d_t, d_t_kp, d_nt, cap_t, d_match, d_nmatches, th=None, strict_lt=False, stream=None):
         """Device-resident brute-force SearchByBoW (one group): enqueue only."""
         return check(

@@ -449,3 +449,31 @@ def test_undistort_kats(oracle):
     # barrel distortion (k1 < 0): the undistorted image extends beyond the frame on every side
     b = oracle.image_bounds(752, 480, K, dist)
     assert b[0] < 0 and b[1] > 752 and b[2] < 0 and b[3] > 480
+
+
+def test_search_by_projection_map_kat(oracle):
+    """SearchByProjection(Frame&, vector<MapPoint*>&) (src/ORBmatcher.cc:38-227): the ratio veto applies only when best and second
+    best sit on the same level; levels [predicted - 1, predicted]; claims in list order."""
+    KP = oracle.KP_DTYPE
+    cur = np.zeros(3, KP)
+    cur["x"], cur["y"], cur["octave"] = [100, 102, 104], [100, 100, 100], [1, 1, 0]
+    dcur = np.zeros((3, 32), np.uint8)
+    dcur[0, 0] = 0x0F   # 4 bits from the query
+    dcur[1, 0] = 0x1F   # 5 bits
+    dcur[2, 0] = 0xFF   # 8 bits, level 0
+    sf = np.array([1.0, 1.2, 1.44], np.float32)
+    q = np.zeros((1, 32), np.uint8)
+    uv = np.array([[101, 100]], np.float32)
+    bounds = (0.0, 640.0, 0.0, 480.0)
+    args = (None, np.array([1], np.int32), np.array([4.0], np.float32), None, dcur, cur, None, None, sf)
+    # best 4 (level 1), second 5 (level 1): 4 > 0.6 * 5 = 3 -> vetoed; with ratio 0.9: 4 > 4.5 false -> matched
+    assert oracle.search_by_projection_map(q, uv, *args, 0.6, bounds, 100)[0] == 0
+    n, com, moc = oracle.search_by_projection_map(q, uv, *args, 0.9, bounds, 100)
+    assert n == 1 and com.tolist() == [0] and moc.tolist() == [0, -1, -1]
+    # feature 1 occupied: second best is now feature 2 on ANOTHER level -> no veto even at ratio 0.1
+    occ = np.array([0, 1, 0], np.uint8)
+    n, com, _ = oracle.search_by_projection_map(q, uv, None, np.array([1], np.int32), np.array([4.0], np.float32), None, dcur, cur, None, occ, sf, 0.1, bounds, 100)
+    assert n == 1 and com.tolist() == [0]
+    # predicted level 2: only levels 1..2 qualify (feature 2 on level 0 is out); predicted level 0: levels -1..0 -> only feature 2
+    n, com, _ = oracle.search_by_projection_map(q, uv, None, np.array([0], np.int32), np.array([4.0], np.float32), None, dcur, cur, None, None, sf, 0.9, bounds, 100)
+    assert n == 1 and com.tolist() == [2]

@@ -115,6 +115,30 @@ def row_n3():
             "gpu_ms_per_call": tg * 1e3, "cpu_oracle_ms_per_call": tc * 1e3, "speedup": tc / tg, "includes": "host grid build, H2D, 2 kernels, D2H"}
 
 
+def row_n3_map():
+    frames = synth.make_stream(480, 640, 2, camera_idx=7)
+    oex = O.OracleExtractor(1000, 1.2, 8, 20, 7)
+    _, kA, dA = oex(frames[0], (0, 1000))
+    _, kB, dB = oex(frames[1], (0, 1000))
+    sf = oex.scale_tables()[0]
+    rng = np.random.default_rng(31)
+    _, mq, _ = O.match_groups(dA, dB, kA["angle"], kB["angle"], 50, 0.7, False, True)
+    ok = mq >= 0
+    shift = np.median(np.stack([kB["x"][mq[ok]] - kA["x"][ok], kB["y"][mq[ok]] - kA["y"][ok]], 1), axis=0)
+    uv = (np.stack([kA["x"], kA["y"]], 1) + shift + rng.normal(0, 2.0, (len(kA), 2))).astype(np.float32)
+    level = kA["octave"].astype(np.int32)
+    radius = np.where(rng.random(len(kA)) < 0.5, 2.5, 4.0).astype(np.float32) * np.float32(3.0)
+    bounds = (0.0, 640.0, 0.0, 480.0)
+    m = ORBmatcher(0.8, True)
+    ref = O.search_by_projection_map(dA, uv, None, level, radius, None, dB, kB, None, None, sf, 0.8, bounds, 100)
+    got = m.SearchByProjectionMapPoints(dA, uv, level, radius, kB, dB, sf, bounds)
+    assert ref[0] == got[0] and ref[1].tolist() == got[1].tolist()
+    tg = timeit(lambda: m.SearchByProjectionMapPoints(dA, uv, level, radius, kB, dB, sf, bounds), 50)
+    tc = timeit(lambda: O.search_by_projection_map(dA, uv, None, level, radius, None, dB, kB, None, None, sf, 0.8, bounds, 100), 20)
+    return {"row": "N3 SearchByProjection(Frame, MapPoints)", "workload": "%d MapPoints vs %d features, th = 3, %d matches" % (len(kA), len(kB), ref[0]),
+            "gpu_ms_per_call": tg * 1e3, "cpu_oracle_ms_per_call": tc * 1e3, "speedup": tc / tg, "includes": "host grid build, H2D, 2 kernels, D2H"}
+
+
 def row_n3_batch():
     """Device-resident batch form: 255 consecutive pairs of a 256-frame extraction batch, grid built on the device."""
     import ctypes as C
@@ -182,5 +206,5 @@ def row_n3_batch():
 
 
 if __name__ == "__main__":
-    for fn in (row_n1, row_n2, row_n3, row_n3_batch):
+    for fn in (row_n1, row_n2, row_n3, row_n3_map, row_n3_batch):
         print(json.dumps(fn()), flush=True)
