@@ -1396,45 +1396,35 @@ int orbm_match_groups(orbm_t* h, const uint8_t* q, int nq, const uint8_t* t, int
         return -2;
       }
   }
-  hipStream_t s = h->stream;
-  if (h->dq.ensure((size_t)nq * 32 + 32) || h->dt.ensure((size_t)nt * 32 + 32) || h->topk.ensure((size_t)(nqe + 1) * kTopK) ||
-      h->nvalid.ensure(nqe + 1) || h->binOf.ensure(nq + 1) || h->mq.ensure(nq + 1) || h->mt.ensure(nt + 1) || h->nm.ensure(1) ||
-      h->qa.ensure(nq + 1) || h->ta.ensure(nt + 1) || h->dqv.ensure(nq + 1) || h->dtv.ensure(nt + 1) || h->qoff.ensure(ngroups + 2) ||
-      h->toff.ensure(ngroups + 2) || h->qidx.ensure(nqe + 1) || h->tidx.ensure(nte + 1))
+  hipStream_t  s       = h->stream;
+  // one packed upload, one packed download (see Arena)
+  const size_t inBytes = (size_t)nq * (32 + 4 + 1) + (size_t)nt * (32 + 4 + 1) + (size_t)(2 * ngroups + 2 + nqe + nte) * 4 + 16 * 16;
+  if (h->in.reserve(inBytes) || h->out.reserve((size_t)(nq + nt + 4) * 4 + 64) || h->topk.ensure((size_t)(nqe + 1) * kTopK) ||
+      h->nvalid.ensure(nqe + 1) || h->binOf.ensure(nq + 1))
     return -3;
-  auto up = [&](void* d, const void* src, size_t bytes) -> hipError_t {
-    return bytes ? hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, s) : hipSuccess;
-  };
-  HIP_TRYM(up(h->dq.p, q, (size_t)nq * 32));
-  HIP_TRYM(up(h->dt.p, t, (size_t)nt * 32));
-  if (q_angle) HIP_TRYM(up(h->qa.p, q_angle, (size_t)nq * 4));
-  if (t_angle) HIP_TRYM(up(h->ta.p, t_angle, (size_t)nt * 4));
-  if (q_valid) HIP_TRYM(up(h->dqv.p, q_valid, nq));
-  if (t_valid) HIP_TRYM(up(h->dtv.p, t_valid, nt));
-  if (grouped) {
-    HIP_TRYM(up(h->qoff.p, q_off, (size_t)(ngroups + 1) * 4));
-    HIP_TRYM(up(h->toff.p, t_off, (size_t)(ngroups + 1) * 4));
-    HIP_TRYM(up(h->qidx.p, q_idx, (size_t)nqe * 4));
-    HIP_TRYM(up(h->tidx.p, t_idx, (size_t)nte * 4));
-  }
   GroupArgs a;
   memset(&a, 0, sizeof(a));
-  a.q = h->dq.p, a.t = h->dt.p, a.nq = nq, a.nt = nt, a.ngroups = ngroups, a.nqe = nqe;
-  a.q_off = grouped ? h->qoff.p : nullptr, a.q_idx = grouped ? h->qidx.p : nullptr;
-  a.t_off = grouped ? h->toff.p : nullptr, a.t_idx = grouped ? h->tidx.p : nullptr;
-  a.q_valid = q_valid ? h->dqv.p : nullptr, a.t_valid = t_valid ? h->dtv.p : nullptr;
-  a.q_angle = h->qa.p, a.t_angle = h->ta.p, a.q_astride = 1, a.t_astride = 1;
+  Arena& in = h->in;
+  a.q = in.put(q, (size_t)nq * 32), a.t = in.put(t, (size_t)nt * 32);
+  a.q_angle = q_angle ? in.put(q_angle, nq) : nullptr, a.t_angle = t_angle ? in.put(t_angle, nt) : nullptr;
+  a.q_valid = q_valid ? in.put(q_valid, nq) : nullptr, a.t_valid = t_valid ? in.put(t_valid, nt) : nullptr;
+  if (grouped) {
+    a.q_off = in.put(q_off, ngroups + 1), a.t_off = in.put(t_off, ngroups + 1);
+    a.q_idx = in.put(q_idx, nqe), a.t_idx = in.put(t_idx, nte);
+  }
+  if (in.off) HIP_TRYM(hipMemcpyAsync(in.d, in.h, in.off, hipMemcpyHostToDevice, s));
+  Arena& out = h->out;
+  a.nmatches = out.put((const int*)nullptr, 4), a.match_t_of_q = out.put((const int*)nullptr, nq), a.match_q_of_t = out.put((const int*)nullptr, nt);
+  a.nq = nq, a.nt = nt, a.ngroups = ngroups, a.nqe = nqe, a.q_astride = 1, a.t_astride = 1;
   a.th = th, a.strict_lt = strict_lt, a.check_ori = check_ori, a.ratio = ratio, a.dstar = prune_bound(th, ratio);
   a.topk = h->topk.p, a.nvalid = h->nvalid.p, a.binOf = h->binOf.p;
-  a.match_t_of_q = h->mq.p, a.match_q_of_t = h->mt.p, a.nmatches = h->nm.p;
   int rc = launch_groups(h, a, nq, s);
   if (rc) return rc;
-  int nm = 0;
-  HIP_TRYM(hipMemcpyAsync(&nm, h->nm.p, 4, hipMemcpyDeviceToHost, s));
-  if (match_t_of_q && nq) HIP_TRYM(hipMemcpyAsync(match_t_of_q, h->mq.p, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
-  if (match_q_of_t && nt) HIP_TRYM(hipMemcpyAsync(match_q_of_t, h->mt.p, (size_t)nt * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRYM(hipMemcpyAsync(out.h, out.d, out.off, hipMemcpyDeviceToHost, s));
   HIP_TRYM(hipStreamSynchronize(s));
-  return nm;
+  if (match_t_of_q && nq) memcpy(match_t_of_q, out.host_of(a.match_t_of_q), (size_t)nq * 4);
+  if (match_q_of_t && nt) memcpy(match_q_of_t, out.host_of(a.match_q_of_t), (size_t)nt * 4);
+  return *out.host_of(a.nmatches);
 }
 
 int orbm_match_bruteforce_device(orbm_t* h, const uint8_t* d_q, const orbx_keypoint_t* d_q_kp, const int* d_nq, int cap_q,
