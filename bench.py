@@ -270,6 +270,14 @@ def main():
                 traffic = int(sum(summ["kernels"][n]["hbm_traffic_MB_per_launch"] for n in names) * 1e6)
         except Exception:
             traffic = None
+        # share of SIMD issue slots the dominant kernel spends on VALU instructions, from the committed SQ-counter pass of the same
+        # command (tools/sq_counters.sh + tools/sq_summary.py): the integer issue rate, not HBM, is this pipeline's ceiling
+        valu_frac = None
+        try:
+            sq = json.load(open(os.path.join(ROOT, "profiles", "r01_sq_summary.json")))
+            valu_frac = sq[kernels[dom].split("+")[0]]["valu_issue_frac"]
+        except Exception:
+            valu_frac = None
         out = {
             "metric": "frames/s ORB extract+match (640x480, 8 lvl, 1000 feat)" if cols == 640 else "frames/s ORB extract+match",
             "value": round(value, 2),
@@ -305,6 +313,7 @@ def main():
                 "traffic": traffic,
                 "algorithmic_bytes_per_launch": per_frame * B,
                 "avg_launch_ms": round(stage[dom], 5),
+                "valu_issue_frac": valu_frac,
             },
             "stage_ms": {k: round(v, 5) for k, v in stage.items()},
             "pipeline_hbm": {
