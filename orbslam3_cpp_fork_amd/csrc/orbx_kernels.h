@@ -1009,6 +1009,11 @@ __global__ __launch_bounds__(256, 6) void k_orient_describe(Bufs b, FrameGeom g,
   const int lane = threadIdx.x & 63, hl = lane & 31, half = lane >> 5;
   const int q = blockIdx.x >> 3, f = (blockIdx.x & 7) + 8 * (q / nbPerFrame);
   if (f >= nframes) return;
+  // the 256 pattern pairs (4 bytes each) go to LDS once per workgroup: the taps are then a short LDS read right where they are
+  // needed instead of 8 registers held across the trigonometry
+  __shared__ uint32_t sPat[256];
+  sPat[threadIdx.x] = reinterpret_cast<const uint32_t*>(pat->v)[threadIdx.x];
+  __syncthreads();
   const int i = (q % nbPerFrame) * kOdKpPerBlock + (threadIdx.x >> 6) * 2 + half;
   // (packed candidate, level, output row) were laid down by k_layout: one load, requested together with the frame's count
   const int  n    = counts[2 * f];
@@ -1041,10 +1046,7 @@ __global__ __launch_bounds__(256, 6) void k_orient_describe(Bufs b, FrameGeom g,
     const int rr = idx / 11, cc = idx - rr * 11;
     win[k]       = *reinterpret_cast<const uint32_t*>(blr + (uint32_t)(inf1.y + rr * blurPitch + cc * 4));
   }
-  // this half-lane's 8 pattern pairs (it tests pair w * 32 + hl in round w): requested up front as well
-  char4 taps[8];
-#pragma unroll
-  for (int w = 0; w < 8; w++) taps[w] = *reinterpret_cast<const char4*>(&pat->v[(w * 32 + hl) * 4]);
+
   // ---- orientation on the raw level
   int m10 = 0, m01 = 0;
   {
@@ -1101,7 +1103,7 @@ __global__ __launch_bounds__(256, 6) void k_orient_describe(Bufs b, FrameGeom g,
   uint32_t       mine = 0;  // half-lane w < 8 ends up with descriptor word w of its keypoint
 #pragma unroll
   for (int w = 0; w < 8; w++) {
-    const char4 p4 = taps[w];
+    const char4 p4 = __builtin_bit_cast(char4, sPat[w * 32 + hl]);
     const float x0 = (float)p4.x, y0 = (float)p4.y, x1 = (float)p4.z, y1 = (float)p4.w;
     const int   r0 = __float2int_rn(x0 * bb + y0 * a), c0 = __float2int_rn(x0 * a - y0 * bb);
     const int   r1 = __float2int_rn(x1 * bb + y1 * a), c1 = __float2int_rn(x1 * a - y1 * bb);
