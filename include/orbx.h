@@ -88,6 +88,15 @@ int orbx_stereo_matches(orbx_t* left, orbx_t* right, const orbx_keypoint_t* kps_
                         const orbx_keypoint_t* kps_right, const uint8_t* desc_right, int n_right, float mb, float mbf, float* u_right,
                         float* depth);
 
+/* The same for every frame pair of two extraction batches, device-resident: the two handles must have run
+ * orbx_extract_batch_device on same-sized batches of at least nframes frames (their pyramids and -- for level 0 -- the caller's
+ * image buffers of those calls are read, so the images must still be there); d_kl / d_dl / d_counts_l and d_kr / d_dr /
+ * d_counts_r are the output buffers of those calls (capacity cap each).  Frame f writes d_u_right / d_depth at [f * cap ..]
+ * and d_kept[f].  The stream must be ordered after both extractions.  Enqueue only. */
+int orbx_stereo_matches_batch_device(orbx_t* left, orbx_t* right, const orbx_keypoint_t* d_kl, const uint8_t* d_dl, const int* d_counts_l,
+                                     const orbx_keypoint_t* d_kr, const uint8_t* d_dr, const int* d_counts_r, int nframes, int cap, float mb,
+                                     float mbf, float* d_u_right, float* d_depth, int* d_kept, void* stream);
+
 /* Stage timing with HIP events recorded on the launch stream between the kernels of every batch:
  * enable (resets the record), run batches, then read the mean milliseconds per stage over the batches
  * recorded since (at most the last 32); returns the number of batches averaged.  Stages: 0 pyramid

@@ -37,6 +37,7 @@ SIGNATURES = {
     "orbx_undistort_keypoints_device": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _vp]),
     "orbx_image_bounds": (_i, [_i, _i, _vp, _vp, _i, _vp]),
     "orbx_stereo_matches": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _f, _f, _vp, _vp]),
+    "orbx_stereo_matches_batch_device": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _vp, _vp, _vp, _vp]),
     "orbx_pyramid_level": (_i, [_vp, _i, _i, _vp, _sz, _ip, _ip]),
     "orbx_set_profiling": (None, [_vp, _i]),
     "orbx_get_stage_ms": (_i, [_vp, _vp]),

@@ -114,6 +114,7 @@ struct orbx_extractor {
   int             lastB    = 0;
   orbx::Bufs      bufs{};
   DevBuf<uint8_t> dPyr, dBlur, dNCh, dStage, dRaw, dDescOut;
+  DevBuf<int>     dStereoSad;
   DevBuf<int2>    dXtab, dYtab;
   DevBuf<int4>    dCellDesc;
   DevBuf<long long> dDbgT;
@@ -360,7 +361,23 @@ int orbx_extractor::ensureWorkspace(int rows, int cols, int B) {
 int orbx_extractor::runResized(const uint8_t* d_imgs, int B, int rows, int cols, size_t step, size_t frameStride, int lap0, int lap1,
                                orbx::KpRec* d_kps, uint8_t* d_desc, int* d_counts, int cap, hipStream_t s) {
   using namespace orbx;
-  if (!resizing(rows, cols)) return run(d_imgs, B, rows, cols, step, frameStride, lap0, lap1, d_kps, d_desc, d_counts, cap, s);
+  if (!resizing(rows, cols)) {
+    // Frames whose rows are not 4-byte aligned (odd widths with a tight step: KITTI's 1241) would put level 0 on the byte-load
+    // paths of FAST / blur / resize.  One device-side pitched copy into an aligned buffer is cheaper (60 MB per 128 frames).
+    const bool al4 = (step % 4 == 0) && (frameStride % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_imgs) & 3) == 0);
+    // ORBX_NO_REPITCH=1 keeps the direct route (byte-load kernel variants) reachable for the parity tests
+    if (al4 || getenv("ORBX_NO_REPITCH")) return run(d_imgs, B, rows, cols, step, frameStride, lap0, lap1, d_kps, d_desc, d_counts, cap, s);
+    const int    pitch = alignUp(cols, 64);
+    const size_t fs    = (size_t)pitch * rows;
+    if (dPre.ensure(fs * B + 256)) return -3;
+    if (frameStride == step * (size_t)rows) {
+      HIP_TRY(hipMemcpy2DAsync(dPre.p, pitch, d_imgs, step, cols, (size_t)rows * B, hipMemcpyDeviceToDevice, s));
+    } else {
+      for (int f = 0; f < B; f++)
+        HIP_TRY(hipMemcpy2DAsync(dPre.p + fs * f, pitch, d_imgs + frameStride * f, step, cols, rows, hipMemcpyDeviceToDevice, s));
+    }
+    return run(dPre.p, B, rows, cols, pitch, fs, lap0, lap1, d_kps, d_desc, d_counts, cap, s);
+  }
   // footprint of a 128 x 16 destination tile must fit the LDS stage of resize_tile (176 x 24 source pixels)
   if ((double)cols / preW * kRsTileW + 6 > kRsLdsW || (double)rows / preH * (kRsTileH - 1) + 3 > kRsLdsH - 1) {
     g_err = "input resize: shrink factor above 1.32 (x) / 1.4 (y) is not supported";
@@ -583,7 +600,7 @@ void orbx_destroy(orbx_t* h) {
   if (h->evValid)
     for (auto& slot : h->ev)
       for (auto& e : slot) hipEventDestroy(e);
-  h->dPyr.release(), h->dBlur.release(), h->dRaw.release(), h->dPre.release(), h->dPreX.release(), h->dPreY.release(), h->dStage.release(), h->dDescOut.release(), h->dXtab.release(), h->dYtab.release();
+  h->dPyr.release(), h->dBlur.release(), h->dStereoSad.release(), h->dRaw.release(), h->dPre.release(), h->dPreX.release(), h->dPreY.release(), h->dStage.release(), h->dDescOut.release(), h->dXtab.release(), h->dYtab.release();
   h->dCellDesc.release(), h->dCellOrder.release(), h->dCellSlot.release(), h->dCellCount.release(), h->dNodeOf.release(), h->dCellOffs.release();
   h->dD.release(), h->dDIndex.release(), h->dNCh.release(), h->dPushOff.release(), h->dMultiOff.release();
   h->dKeptRank.release(), h->dVA.release(), h->dVB.release(), h->dCandCount.release(), h->dLvlCount.release(), h->dOutIdx.release();
@@ -874,6 +891,7 @@ int orbx_stereo_matches(orbx_t* left, orbx_t* right, const orbx_keypoint_t* kl, 
     HIP_TRY(hipMemcpyAsync(ddr.p, dr, (size_t)nr * 32, hipMemcpyHostToDevice, s));
   }
   StereoArgs a;
+  memset(&a, 0, sizeof(a));
   a.kl = dkl.p, a.kr = dkr.p, a.dl = ddl.p, a.dr = ddr.p, a.nl = nl, a.nr = nr, a.nrows = left->geom.rows, a.mb = mb, a.mbf = mbf;
   a.pyrL0 = left->bufs.img0, a.pyrR0 = right->bufs.img0, a.pitch0 = left->bufs.img0Pitch;
   if (right->bufs.img0Pitch != left->bufs.img0Pitch) {
@@ -892,6 +910,43 @@ int orbx_stereo_matches(orbx_t* left, orbx_t* right, const orbx_keypoint_t* kl, 
   HIP_TRY(hipStreamSynchronize(s));
   dkl.release(), dkr.release(), ddl.release(), ddr.release(), du.release(), dd.release(), dsad.release(), dkept.release();
   return kept;
+}
+
+// Frame::ComputeStereoMatches for every frame of the two handles' last extraction batches, device-resident (see include/orbx.h).
+int orbx_stereo_matches_batch_device(orbx_t* left, orbx_t* right, const orbx_keypoint_t* d_kl, const uint8_t* d_dl, const int* d_counts_l,
+                                     const orbx_keypoint_t* d_kr, const uint8_t* d_dr, const int* d_counts_r, int nframes, int cap, float mb,
+                                     float mbf, float* d_u_right, float* d_depth, int* d_kept, void* stream) {
+  using namespace orbx;
+  if (!left || !right || !d_kl || !d_dl || !d_counts_l || !d_kr || !d_dr || !d_counts_r || nframes < 0 || cap < 1 || !d_u_right || !d_depth ||
+      !d_kept || !(mb > 0.f)) {
+    g_err = "orbx_stereo_matches_batch_device: bad arguments";
+    return -2;
+  }
+  if (!left->haveGeom || !right->haveGeom || left->lastB < nframes || right->lastB < nframes || left->geom.rows != right->geom.rows ||
+      left->geom.cols != right->geom.cols || left->nlevels != right->nlevels || left->device != right->device ||
+      left->bufs.img0Pitch != right->bufs.img0Pitch) {
+    g_err = "orbx_stereo_matches_batch_device: both extractors must hold the pyramids of a same-sized batch on the same device";
+    return -2;
+  }
+  if (cap > 65535) {
+    g_err = "orbx_stereo_matches_batch_device: more than 65535 keypoints per frame";
+    return -2;
+  }
+  if (nframes == 0) return 0;
+  HIP_TRY(hipSetDevice(left->device));
+  if (left->dStereoSad.ensure((size_t)nframes * cap)) return -3;
+  hipStream_t s = stream ? (hipStream_t)stream : left->stream;
+  StereoArgs  a;
+  memset(&a, 0, sizeof(a));
+  a.kl = (const KpRec*)d_kl, a.kr = (const KpRec*)d_kr, a.dl = d_dl, a.dr = d_dr, a.nrows = left->geom.rows, a.mb = mb, a.mbf = mbf;
+  a.pyrL0 = left->bufs.img0, a.pyrR0 = right->bufs.img0, a.pitch0 = left->bufs.img0Pitch;
+  a.pyrL = left->bufs.pyr, a.pyrR = right->bufs.pyr, a.uRight = d_u_right, a.depth = d_depth, a.sad = left->dStereoSad.p;
+  a.cap = cap, a.countsL = d_counts_l, a.countsR = d_counts_r, a.img0StrideL = left->bufs.img0FrameStride;
+  a.img0StrideR = right->bufs.img0FrameStride, a.pyrBytes = left->geom.pyrBytes;
+  hipLaunchKernelGGL(k_stereo_match, dim3((cap + 3) / 4, nframes), dim3(256), 0, s, a, left->geom);
+  hipLaunchKernelGGL(k_stereo_cut, dim3(nframes), dim3(256), 0, s, a, d_kept);
+  HIP_TRY(hipGetLastError());
+  return 0;
 }
 
 // PMC calibration hook (see k_calib_read): reads `nbytes` of a scratch buffer with `width` bytes per lane per load.

@@ -1152,10 +1152,28 @@ struct StereoArgs {
   const uint8_t *pyrL, *pyrR;    // levels >= 1 (frame 0 of each handle)
   float *        uRight, *depth;
   int*           sad;            // best SAD distance per left keypoint, -1 = not a match
+  // batch form (cap > 0): blockIdx.y = frame f of the two handles' last extraction batch; every array is [frames][cap],
+  // counts are the extraction batches' [frames][2] arrays
+  int            cap;
+  const int *    countsL, *countsR;
+  long long      img0StrideL, img0StrideR, pyrBytes;
 };
 
-__global__ __launch_bounds__(256) void k_stereo_match(StereoArgs a, FrameGeom g) {
-  const int iL = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+__device__ __forceinline__ StereoArgs stereo_view(const StereoArgs& a, int f) {
+  if (a.cap <= 0) return a;
+  StereoArgs      v  = a;
+  const long long fc = (long long)f * a.cap;
+  v.kl = a.kl + fc, v.kr = a.kr + fc, v.dl = a.dl + fc * 32, v.dr = a.dr + fc * 32;
+  v.nl = a.countsL[2 * f], v.nr = a.countsR[2 * f];
+  v.pyrL0 = a.pyrL0 + f * a.img0StrideL, v.pyrR0 = a.pyrR0 + f * a.img0StrideR;
+  v.pyrL = a.pyrL + f * a.pyrBytes, v.pyrR = a.pyrR + f * a.pyrBytes;
+  v.uRight = a.uRight + fc, v.depth = a.depth + fc, v.sad = a.sad + fc;
+  return v;
+}
+
+__global__ __launch_bounds__(256) void k_stereo_match(StereoArgs a0, FrameGeom g) {
+  const StereoArgs a  = stereo_view(a0, blockIdx.y);
+  const int        iL = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (iL >= a.nl) return;
   const KpRec kpL    = a.kl[iL];
   const int   levelL = kpL.octave;
@@ -1255,9 +1273,11 @@ __global__ __launch_bounds__(256) void k_stereo_match(StereoArgs a, FrameGeom g)
   }
 }
 
-__global__ __launch_bounds__(256) void k_stereo_cut(StereoArgs a, int* kept) {
-  __shared__ int sMedian, sCount;
-  const int      tid = threadIdx.x;
+__global__ __launch_bounds__(256) void k_stereo_cut(StereoArgs a0, int* kept0) {
+  const StereoArgs a    = stereo_view(a0, blockIdx.x);
+  int*             kept = kept0 + blockIdx.x;
+  __shared__ int   sMedian, sCount;
+  const int        tid = threadIdx.x;
   if (tid == 0) sMedian = -1, sCount = 0;
   __syncthreads();
   int cnt = 0;

@@ -136,3 +136,35 @@ def test_batch_device_matches_single(oracle, gpu_ex):
         k = d_kps[f, :n].cpu().numpy().view(KP_DTYPE).reshape(-1)
         d = d_desc[f, :n].cpu().numpy()
         assert_same_output(oex(frames[f], (0, 1000)), (mono, k, d), "batch frame %d" % f)
+
+
+@pytest.mark.parametrize("repitch", [True, False])
+def test_unaligned_batch(oracle, repitch, monkeypatch):
+    """Frames with an odd width and a tight step (KITTI's 1241): the batch entry repitches them on the device; with
+    ORBX_NO_REPITCH=1 the byte-load variants of FAST / blur / resize take level 0 directly.  Same results either way."""
+    import torch
+
+    from orbslam3_cpp_fork_amd import synth
+    from orbslam3_cpp_fork_amd.extractor import ORBextractor
+
+    if not repitch:
+        monkeypatch.setenv("ORBX_NO_REPITCH", "1")
+    B, rows, cols = 2, 241, 397
+    fr = np.stack([synth.make_frame(rows, cols, 3, i) for i in range(B)])
+    ex = ORBextractor(600)
+    cap = ex.max_keypoints(rows, cols)
+    dev = torch.device("cuda", 0)
+    d = torch.from_numpy(fr).to(dev)
+    kps = torch.zeros((B, cap, 7), device=dev)
+    desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
+    cnt = torch.zeros((B, 2), dtype=torch.int32, device=dev)
+    ex.extract_batch_device(d, B, rows, cols, cols, rows * cols, kps, desc, cnt, cap, (0, 1000), stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    oex = oracle.OracleExtractor(600, 1.2, 8, 20, 7)
+    for f in range(B):
+        rc, k, dd = oex(fr[f], (0, 1000))
+        n = int(cnt[f, 0])
+        assert n == len(k) and int(cnt[f, 1]) == rc
+        got = np.frombuffer(kps[f, :n].cpu().numpy().tobytes(), oracle.KP_DTYPE)
+        assert got.tobytes() == k.tobytes() and (desc[f, :n].cpu().numpy() == dd).all()
+    ex.close()
