@@ -165,3 +165,33 @@ def test_image_bounds_host(oracle):
         ([718.856, 718.856, 607.1928, 185.2157], [0.0, 0.0, 0.0, 0.0], (1241, 376)),
     ):
         assert list(ComputeImageBounds(w, h, K, dist)) == oracle.image_bounds(w, h, K, dist).tolist()
+
+
+def test_bad_arguments_are_rejected_before_the_device():
+    """Argument errors come back as -2 without touching the GPU (same convention as the extractor: -1 empty, -2 bad args, -3 HIP)."""
+    import ctypes as C
+
+    from orbslam3_cpp_fork_amd import _lib
+
+    L = _lib.lib()
+    h = C.c_void_p()
+    one = np.zeros(4, np.float32)
+    assert L.orbv_create(None, 10, 6, 0, None, None, None, None, 0) == -2
+    assert L.orbv_create(C.byref(h), 10, 6, 3, None, None, None, None, 0) == -2  # arrays missing
+    assert L.orbv_load_text(C.byref(h), None, 0) == -2
+    assert L.orbv_transform(None, None, 0, 4, None, None, None, None, None, None, None) == -2
+    assert L.orbx_image_bounds(640, 480, None, None, 0, _lib.ptr(one)) == -2
+    assert L.orbx_image_bounds(640, 480, _lib.ptr(one), None, 3, _lib.ptr(one)) == -2  # coefficients promised but missing
+    assert L.orbx_set_input_resize(None, 600, 350) == -2
+    assert L.orbx_undistort_keypoints(None, None, 0, None, None, 0, None) == -2
+    assert L.orbm_search_by_projection(None, None, None, None, None, None, None, 0, None, None, None, None, 0, None, 8, 15.0, 0, 0.0, 0.0, 1.0, 0.0, 1.0, 100, 1, None, None) == -2
+    assert L.orbm_search_by_projection_map(None, None, None, None, None, None, None, 0, None, None, None, None, 0, None, 8, 0.8, 0.0, 1.0, 0.0, 1.0, 100, None, None) == -2
+    assert L.orbm_assign_features_to_grid_device(None, None, None, 1, 16, 0.0, 1.0, 0.0, 1.0, None, None, None, None, None) == -2
+    assert L.orbx_stereo_matches_batch_device(None, None, None, None, None, None, None, None, 1, 16, 0.5, 300.0, None, None, None, None) == -2
+    # vocabulary text header checks happen on the host, before any allocation
+    import tempfile
+
+    with tempfile.NamedTemporaryFile("w", suffix=".txt", delete=False) as f:
+        f.write("30 6 0 0\n")  # k > 20 (TemplatedVocabulary.h:1358-1362)
+    assert L.orbv_load_text(C.byref(h), f.name.encode(), 0) == -2
+    os.unlink(f.name)
