@@ -171,10 +171,16 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-match", action="store_true", help="extract only")
     ap.add_argument("--lanes", type=int, default=1, help="chunks in flight (each on its own HIP stream and handles)")
+    ap.add_argument("--rows", action="store_true", help="measure the SURVEY 8(f) rows N1-N3 (device path vs the CPU restatement on the same inputs) "
+                    "instead of the headline workload: one JSON line per row (tests/measure_next_rows.py)")
     ap.add_argument("--bow", action="store_true", help="SearchByBoW proper: add ORBVocabulary::transform (synthetic k=10, L=6 tree) per frame and match "
                     "inside the FeatureVector groups instead of brute force (not the BASELINE configuration; reported as its own workload)")
     args = ap.parse_args()
 
+    if args.rows:
+        from tests import measure_next_rows
+
+        return measure_next_rows.main()
     if args.workload.startswith("kitti_stereo"):
         if int(os.environ.get("WORLD_SIZE", "1")) > 1:
             raise SystemExit("the stereo workload is single-GPU (pairs shard like frames; not wired into the multi-rank path)")

@@ -1,3 +1,4 @@
+"""Single-call latency of the host-pointer SearchByBoW entry point against the CPU restatement (GPU box: python tests/measure_match_latency.py)."""
 import os, sys, time, numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 from oracle import oracle_py as O

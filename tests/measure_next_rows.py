@@ -1,7 +1,8 @@
 """Measurement of the SURVEY 8(f) rows built so far (N1 stereo matches, N2 BoW transform, N3 SearchByProjection): the device
 path against the CPU restatement (oracle, one thread) on the same inputs, on this box.  One JSON line per row.
 N1 / N3 are host-pointer, synchronous entry points (H2D + kernels + D2H per call); N2 is the device-batch entry point.
-Usage (GPU box): python tools/bench_next_rows.py > gpurun_out/next_rows.jsonl
+Lives under tests/ because it uses the oracle (as checker and as the timed CPU baseline); run it through
+`python bench.py --rows` (GPU box), which prints one JSON line per row.
 """
 import json
 import os
@@ -26,6 +27,11 @@ def timeit(fn, reps):
     for _ in range(reps):
         fn()
     return (time.perf_counter() - t) / reps
+
+
+def main():
+    for fn in (row_n1, row_n2, row_n3, row_n3_map, row_n3_batch):
+        print(json.dumps(fn()), flush=True)
 
 
 def row_n1():
@@ -206,5 +212,4 @@ def row_n3_batch():
 
 
 if __name__ == "__main__":
-    for fn in (row_n1, row_n2, row_n3, row_n3_map, row_n3_batch):
-        print(json.dumps(fn()), flush=True)
+    main()
