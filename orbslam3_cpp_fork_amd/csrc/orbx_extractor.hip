@@ -320,6 +320,9 @@ int orbx_extractor::makeGeometry(int rows, int cols) {
     const int fixed = kOctSortWork * 4, nodeBytes = maxCap * kOctNodeBytes;
     if (fixed + nodeBytes + 2 * 512 <= 20224) {
       octLdsNodeCap = maxCap, octLdsBytes = 20224, octLdsPtsCap = (octLdsBytes - fixed - nodeBytes) / 2;
+    } else if (fixed + nodeBytes + 2 * 4096 <= 40960) {
+      // larger quotas (2000 features: 30 KB of node state): 4 problems per CU, and 4096 point labels still ride along
+      octLdsNodeCap = maxCap, octLdsPtsCap = 4096, octLdsBytes = fixed + nodeBytes + 2 * octLdsPtsCap;
     } else if (fixed + nodeBytes <= 65536) {
       octLdsNodeCap = maxCap, octLdsBytes = fixed + nodeBytes, octLdsPtsCap = 0;
     } else {
