@@ -285,3 +285,47 @@ def test_search_by_projection_map_points(oracle, stereo, th):
     ref = oracle.search_by_projection_map(dA2, uv, xr, level, big, valid, dB2, kB, ur, occ, sf, 0.8, bounds, 100)
     got = ORBmatcher(0.8, True).SearchByProjectionMapPoints(dA2, uv, level, big, kB, dB2, sf, bounds, mp_valid=valid, mp_proj_xr=xr, cur_u_right=ur, cur_occupied=occ)
     assert got[0] == ref[0] and got[1].tolist() == ref[1].tolist() and got[2].tolist() == ref[2].tolist()
+
+
+def test_projection_searches_random_scenes(oracle):
+    """Many small random scenes for both SearchByProjection forms: clustered positions, few distinct descriptors (ties, vetoes,
+    exhausted truncated lists), random validity / occupancy / stereo bands -- the claim logic must follow the sequential walk."""
+    from orbslam3_cpp_fork_amd.matcher import ORBmatcher
+
+    sf = (np.float32(1.2) ** np.arange(8)).astype(np.float32)
+    bounds = (0.0, 640.0, 0.0, 480.0)
+    for seed in range(24):
+        rng = np.random.default_rng(1000 + seed)
+        n1, n2 = int(rng.integers(40, 500)), int(rng.integers(40, 500))
+        ncl = int(rng.integers(3, 30))
+        centers = rng.uniform(40, 440, (ncl, 2))
+        cur = np.zeros(n2, oracle.KP_DTYPE)
+        pc = centers[rng.integers(0, ncl, n2)] + rng.normal(0, 12, (n2, 2))
+        cur["x"], cur["y"] = pc[:, 0].astype(np.float32), pc[:, 1].astype(np.float32)
+        cur["octave"], cur["angle"] = rng.integers(0, 8, n2), rng.uniform(0, 360, n2).astype(np.float32)
+        base = rng.integers(0, 256, (int(rng.integers(2, 12)), 32), dtype=np.uint8)
+        dcur = base[rng.integers(0, len(base), n2)].copy()
+        dcur[:, :2] ^= rng.integers(0, 8, (n2, 2)).astype(np.uint8)
+        dq = dcur[rng.integers(0, n2, n1)].copy()
+        dq[:, 31] ^= rng.integers(0, 4, n1).astype(np.uint8)
+        uv = (centers[rng.integers(0, ncl, n1)] + rng.normal(0, 10, (n1, 2))).astype(np.float32)
+        octv = rng.integers(0, 8, n1).astype(np.int32)
+        ang = rng.uniform(0, 360, n1).astype(np.float32)
+        valid = (rng.random(n1) < 0.9).astype(np.uint8)
+        occ = (rng.random(n2) < 0.15).astype(np.uint8)
+        stereo = seed % 3 == 0
+        ur = np.where(rng.random(n2) < 0.6, cur["x"] - rng.uniform(0, 30, n2), -1.0).astype(np.float32) if stereo else None
+        invz = rng.uniform(0.01, 1.0, n1).astype(np.float32)
+        th = float(rng.choice([7.0, 15.0, 40.0]))
+        direction = int(seed % 3)
+        ref = oracle.search_by_projection(dq, uv, invz, octv, ang, valid, dcur, cur, ur, occ, sf, th, direction, 25.0, bounds, 100, True)
+        got = ORBmatcher(0.9, True).SearchByProjection(dq, uv, octv, ang, cur, dcur, sf, th, bounds, last_valid=valid, last_invz=invz, cur_u_right=ur,
+                                                       cur_occupied=occ, direction=direction, mbf=25.0)
+        assert got[0] == ref[0] and got[1].tolist() == ref[1].tolist() and got[2].tolist() == ref[2].tolist(), seed
+        radius = (np.where(rng.random(n1) < 0.5, 2.5, 4.0) * rng.choice([1.0, 3.0, 8.0])).astype(np.float32)
+        xr = (uv[:, 0] - rng.uniform(0, 30, n1)).astype(np.float32) if stereo else None
+        ratio = float(rng.choice([0.6, 0.8, 0.9]))
+        ref = oracle.search_by_projection_map(dq, uv, xr, octv, radius, valid, dcur, cur, ur, occ, sf, ratio, bounds, 100)
+        got = ORBmatcher(ratio, True).SearchByProjectionMapPoints(dq, uv, octv, radius, cur, dcur, sf, bounds, mp_valid=valid, mp_proj_xr=xr, cur_u_right=ur,
+                                                                  cur_occupied=occ)
+        assert got[0] == ref[0] and got[1].tolist() == ref[1].tolist() and got[2].tolist() == ref[2].tolist(), seed
