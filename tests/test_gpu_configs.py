@@ -130,8 +130,8 @@ def test_stereo_matches_on_device_pyramids(oracle):
         assert (u0.view(np.uint32) == u1.view(np.uint32)).all() and (d0.view(np.uint32) == d1.view(np.uint32)).all()
 
 
-@pytest.mark.parametrize("src,dst", [((480, 752), (350, 600)), ((240, 320), (300, 400)), ((480, 640), (400, 560))])
-def test_input_resize_fused(oracle, src, dst):
+@pytest.mark.parametrize("src,dst,nf", [((480, 752), (350, 600), 1000), ((480, 752), (350, 600), 5000), ((240, 320), (300, 400), 1000), ((480, 640), (400, 560), 1000)])
+def test_input_resize_fused(oracle, src, dst, nf):
     """N4 (first half): the cv::resize that System::TrackMonocular applies when Camera.newWidth/newHeight are set
     (src/System.cc:472-478; EuRoC.yaml 752x480 -> 600x350) runs on the device in front of the extractor."""
     from orbslam3_cpp_fork_amd import synth
@@ -139,9 +139,9 @@ def test_input_resize_fused(oracle, src, dst):
 
     img = synth.make_frame(src[0], src[1], camera_idx=2, frame_idx=5)
     small = oracle.resize_linear(img, dst[1], dst[0])
-    oex = oracle.OracleExtractor(1000, 1.2, 8, 20, 7)
+    oex = oracle.OracleExtractor(nf, 1.2, 8, 20, 7)  # nf = 5000: the mono-initialisation extractor of BASELINE config 1 (src/Tracking.cc:1537-1547)
     ref = oex(small, (0, 1000))
-    gex = ORBextractor(1000, 1.2, 8, 20, 7)
+    gex = ORBextractor(nf, 1.2, 8, 20, 7)
     gex.set_input_resize(dst[1], dst[0])
     got = gex(img, None, (0, 1000))
     assert got[0] == ref[0] and len(got[1]) == len(ref[1])
