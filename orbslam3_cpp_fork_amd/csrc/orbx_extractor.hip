@@ -464,22 +464,22 @@ int orbx_extractor::run(const uint8_t* d_imgs, int B, int rows, int cols, size_t
     // tile geometry of this image size: tiles are staged from the aligned column below iniX (up to +3 columns)
     int maxW = 0, maxH = 0;
     for (int l = 0; l < g.nlevels; l++) maxW = std::max(maxW, g.lv[l].wCell), maxH = std::max(maxH, g.lv[l].hCell);
-    const bool    small = maxW + 9 <= 52 && ((maxW + 9 + 3) / 4) * (maxH + 6) <= 3 * 256;
+    const bool    small = maxW + 9 <= 52 && ((maxW + 9 + 3) / 4) * (maxH + 6) <= kFastSmallPre * kFastThreads;
     const int     tsSel = small ? 52 : kFastTileMax;
     orbx::FastLds fl;
     fl.tileBytes = alignUp(tsSel * (maxH + 6), 16);
     fl.maxInt    = alignUp(maxW * maxH, 2);
     fl.kpCap     = ((maxW + 1) / 2) * ((maxH + 1) / 2) + 64;
     const size_t ldsBytes = 2 * (size_t)fl.tileBytes + 2 * (size_t)(fl.maxInt + fl.kpCap);
-#define ORBX_LAUNCH_FAST(AL, NP, TS) hipLaunchKernelGGL((k_fast_cells<AL, NP, TS>), grid, dim3(256), ldsBytes, s, b, g, t1, t2, fastGrid, dbg, fl)
+#define ORBX_LAUNCH_FAST(AL, NP, TS) hipLaunchKernelGGL((k_fast_cells<AL, NP, TS>), grid, dim3(kFastThreads), ldsBytes, s, b, g, t1, t2, fastGrid, dbg, fl)
     if (al4) {
       if (small)
-        ORBX_LAUNCH_FAST(true, 3, 52);
+        ORBX_LAUNCH_FAST(true, kFastSmallPre, 52);
       else
         ORBX_LAUNCH_FAST(true, kFastPrefetchMax, kFastTileMax);
     } else {
       if (small)
-        ORBX_LAUNCH_FAST(false, 3, 52);
+        ORBX_LAUNCH_FAST(false, kFastSmallPre, 52);
       else
         ORBX_LAUNCH_FAST(false, kFastPrefetchMax, kFastTileMax);
     }

@@ -319,7 +319,9 @@ __device__ __forceinline__ int fast_score_pm(const uint8_t* __restrict__ c, int 
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 constexpr int kFastCellsPerBlock = 1;  // cells walked by one (persistent) workgroup
-constexpr int kFastPrefetchMax   = 7;  // tile dwords a thread may hold in flight: ceil(20 * 77 / 256) for the largest tile
+constexpr int kFastThreads       = 128;  // workgroup of k_fast_cells
+constexpr int kFastPrefetchMax   = 14;   // tile dwords a thread may hold in flight for the largest tile (20 x 77 dwords)
+constexpr int kFastSmallPre      = 6;    // ... for the 52-byte-stride instantiation (13 x 59 dwords)  // tile dwords a thread may hold in flight: ceil(20 * 77 / 256) for the largest tile
 
 struct FastCell {
   bool           valid;  // false: padding slot or a cell the reference skips (:782-793) / that has no interior
@@ -376,7 +378,7 @@ __device__ __forceinline__ void fast_prefetch(const FastCell& c, int tid, uint32
   if (!c.valid) return;
 #pragma unroll
   for (int k = 0; k < NPRE; k++) {
-    const int idx = tid + k * 256;
+    const int idx = tid + k * kFastThreads;
     if (idx < c.n4) {
       const int      y = div_magic(idx, c.mT4), x = (idx - y * c.tw4) * 4;
       const uint8_t* src = c.img + (long long)y * c.pitch + x;
@@ -406,7 +408,7 @@ struct FastLds {
 };
 
 template <bool AL4, int NPRE, int TS>
-__global__ __launch_bounds__(256, TS <= 52 ? 8 : 5) void k_fast_cells(Bufs b, FrameGeom g, int iniTh, int minTh, int nslots, int dbgSkip, FastLds fl) {
+__global__ __launch_bounds__(kFastThreads, TS <= 52 ? 8 : 5) void k_fast_cells(Bufs b, FrameGeom g, int iniTh, int minTh, int nslots, int dbgSkip, FastLds fl) {
   extern __shared__ __align__(16) uint8_t fastLds[];
   uint8_t*        tile     = fastLds;                  // pixels, row stride TS
   uint8_t*        score    = fastLds + fl.tileBytes;   // corner score (0 = not a corner at lowTh)
@@ -444,7 +446,7 @@ __global__ __launch_bounds__(256, TS <= 52 ? 8 : 5) void k_fast_cells(Bufs b, Fr
     // registers -> LDS (TS is a multiple of 4: aligned; spill past tw stays inside the row)
 #pragma unroll
     for (int k = 0; k < NPRE; k++) {
-      const int idx = tid + k * 256;
+      const int idx = tid + k * kFastThreads;
       if (idx < cur.n4) {
         const int y = div_magic(idx, cur.mT4), x = (idx - y * cur.tw4) * 4;
         *reinterpret_cast<uint32_t*>(tile + y * ts + x)  = pre[k];
@@ -465,7 +467,7 @@ __global__ __launch_bounds__(256, TS <= 52 ? 8 : 5) void k_fast_cells(Bufs b, Fr
     // <=> max over the pairs of min(pair) < lo, and symmetrically for hi.
     const int  npairs = (npix + 1) >> 1;
     const pk16 tpk    = pk_pair(lowTh, lowTh);
-    for (int j = tid; j < ((npairs + 63) & ~63); j += 256) {
+    for (int j = tid; j < ((npairs + 63) & ~63); j += kFastThreads) {
       bool keepA = false, keepB = false;
       int  idxA = 0, idxB = 0;
       if (j < npairs && !(dbgSkip & 1)) {
@@ -507,7 +509,7 @@ __global__ __launch_bounds__(256, TS <= 52 ? 8 : 5) void k_fast_cells(Bufs b, Fr
     lds_barrier();
     // Pass 2 -- full corner score of the survivors
     const int ncand = candCount;
-    for (int k = tid; k < ((dbgSkip & 2) ? 0 : ncand); k += 256) {
+    for (int k = tid; k < ((dbgSkip & 2) ? 0 : ncand); k += kFastThreads) {
       const int idx = candList[k];
       const int q = div_magic(idx, mIw), y = 3 + q, x = ox3 + idx - q * iw;
       const int sc = fast_score_pm(tl + y * ts + x, ts);
@@ -515,7 +517,7 @@ __global__ __launch_bounds__(256, TS <= 52 ? 8 : 5) void k_fast_cells(Bufs b, Fr
     }
     lds_barrier();
     // Pass 3 -- strict 3x3 NMS under both thresholds, over the survivors only.  Flags go to a sparse list.
-    for (int k = tid; k < ((ncand + 63) & ~63); k += 256) {
+    for (int k = tid; k < ((ncand + 63) & ~63); k += kFastThreads) {
       bool f1 = false, f2 = false;
       int  idx = 0;
       if (k < ncand) {
@@ -555,7 +557,7 @@ __global__ __launch_bounds__(256, TS <= 52 ? 8 : 5) void k_fast_cells(Bufs b, Fr
     // with a smaller pixel index.  The list is short (a few to a few dozen entries per cell).
     uint32_t* out = b.slots + (long long)f * g.totalSlots + slotOff;
     if (tid == 0) b.cellCount[(long long)f * g.totalCells + cur.cell] = cnt1 > 0 ? cnt1 : cnt2;
-    for (int e = tid; e < nk; e += 256) {
+    for (int e = tid; e < nk; e += kFastThreads) {
       const unsigned me = kpList[e];
       if (me & selB) {
         const int idx = me & 0x3fff;
