@@ -321,7 +321,7 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 constexpr int kFastCellsPerBlock = 1;  // cells walked by one (persistent) workgroup
 constexpr int kFastThreads       = 128;  // workgroup of k_fast_cells
 constexpr int kFastPrefetchMax   = 14;   // tile dwords a thread may hold in flight for the largest tile (20 x 77 dwords)
-constexpr int kFastSmallPre      = 6;    // ... for the 52-byte-stride instantiation (13 x 59 dwords)  // tile dwords a thread may hold in flight: ceil(20 * 77 / 256) for the largest tile
+constexpr int kFastSmallPre      = 6;    // ... for the 52-byte-stride instantiation (13 x 59 dwords)
 
 struct FastCell {
   bool           valid;  // false: padding slot or a cell the reference skips (:782-793) / that has no interior
