@@ -282,9 +282,9 @@ int orbx_extractor::makeGeometry(int rows, int cols) {
   HIP_TRY(hipMemcpy(dCellOrder.p, cellOrder.data(), cellOrder.size() * sizeof(int), hipMemcpyHostToDevice));
   // pre-decoded geometry per order slot (FastCellDesc in orbx_kernels.h)
   {
-    std::vector<int4> desc(2 * cellOrder.size());
+    std::vector<int4> desc(3 * cellOrder.size());
     for (size_t sidx = 0; sidx < cellOrder.size(); sidx++) {
-      int4 d0 = make_int4(-1, 0, 0, 0), d1 = make_int4(0, 0, 0, 0);
+      int4 d0 = make_int4(-1, 0, 0, 0), d1 = make_int4(0, 0, 0, 0), d2 = make_int4(0, 0, 0, 0);
       const int cell = cellOrder[sidx];
       if (cell >= 0) {
         int l = 0;
@@ -300,8 +300,13 @@ int orbx_extractor::makeGeometry(int rows, int cols) {
         }
         d0 = make_int4(cell, l, iniX | (iniY << 16), tw | (th << 8) | (valid << 16));
         d1 = make_int4((ci_j * L.wCell) | ((ci_i * L.hCell) << 16), L.slotBase + cellSlot[cell], L.pyrOff + iniY * L.pitch + iniX, L.pitch);
+        if (valid) {  // dividers of the kernel's idx -> (row, column) maps (div_magic): tile dwords per row, interior width
+          auto magic = [](unsigned d) { return d == 1 ? 0u : 0xffffffffu / d + 1u; };
+          const unsigned tw4a = (unsigned)(((iniX & 3) + tw + 3) >> 2), tw4b = (unsigned)((tw + 3) >> 2);
+          d2 = make_int4((int)(0xffffffffu / tw4a + 1u), (int)(0xffffffffu / tw4b + 1u), (int)magic((unsigned)(tw - 6)), 0);
+        }
       }
-      desc[2 * sidx] = d0, desc[2 * sidx + 1] = d1;
+      desc[3 * sidx] = d0, desc[3 * sidx + 1] = d1, desc[3 * sidx + 2] = d2;
     }
     if (dCellDesc.ensure(desc.size() + 2)) return -3;
     HIP_TRY(hipMemcpy(dCellDesc.p, desc.data(), desc.size() * sizeof(int4), hipMemcpyHostToDevice));

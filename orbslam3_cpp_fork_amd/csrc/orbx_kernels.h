@@ -40,7 +40,7 @@ struct Bufs {
   const int2*    ytab;
   const int*     cellSlot;   // [totalCells] slot base of each cell inside the frame's slot array
   const int*     cellOrder;  // [fastGrid] XCD-aware launch order of the FAST cells (-1 = padding)
-  const int4*    cellDesc;   // [fastGrid][2] pre-decoded cell geometry for that order (see FastCellDesc)
+  const int4*    cellDesc;   // [fastGrid][3] pre-decoded cell geometry for that order (see fast_decode)
   uint32_t*      slots;      // [B][totalSlots] per-cell candidate slots written by FAST
   int*           cellCount;  // [B][totalCells]
   // quadtree workspace, per frame: point arrays [totalSlots], node arrays [totalNodes]
@@ -327,15 +327,16 @@ struct FastCell {
   bool           valid;  // false: padding slot or a cell the reference skips (:782-793) / that has no interior
   int            cell, level, ci_i, ci_j, tw, th, iw, ih, pitch, n4, tw4;
   int            ox;  // the tile is staged from the 4-byte aligned column below iniX: cell column x sits at LDS column x + ox
-  unsigned       mT4;
+  unsigned       mT4, mIw;
   const uint8_t* img;  // row 0 of the tile at the ALIGNED column (AL4) / at iniX (byte path, ox = 0)
 };
 
-// Host-built descriptor of one order slot (two int4 = 32 bytes, fetched with one scalar load):
+// Host-built descriptor of one order slot (three int4, scalar loads):
 //   d0 = {cell (-1 = padding), level, iniX | iniY << 16, tw | th << 8 | valid << 16}
 //   d1 = {x offset | y offset << 16 of the cell inside the level (ci_j * wCell, ci_i * hCell),
 //         first candidate slot of the cell inside the frame's slot array, byte offset of (iniX, iniY) inside the
 //         frame's pyramid block (levels >= 1), row pitch (levels >= 1)}
+//   d2 = {div_magic dividers: tile dwords per row (aligned staging), the same for byte staging, interior width; 0}
 // It replaces a per-cell walk over FrameGeom::lv[] (a chain of dependent scalar loads) done twice per cell.
 template <bool AL4>
 __device__ __forceinline__ FastCell fast_decode(const Bufs& b, const FrameGeom& g, int slot, int nslots, int f, int* xoff, int* yoff,
@@ -344,7 +345,7 @@ __device__ __forceinline__ FastCell fast_decode(const Bufs& b, const FrameGeom& 
   c.valid = false;
   c.cell  = -1;
   if (slot >= nslots) return c;
-  const int4 d0 = b.cellDesc[2 * slot], d1 = b.cellDesc[2 * slot + 1];
+  const int4 d0 = b.cellDesc[3 * slot], d1 = b.cellDesc[3 * slot + 1], d2 = b.cellDesc[3 * slot + 2];
   c.cell = d0.x;
   if (c.cell < 0) return c;
   c.level = d0.y;
@@ -364,7 +365,8 @@ __device__ __forceinline__ FastCell fast_decode(const Bufs& b, const FrameGeom& 
   }
   c.tw4 = (c.ox + c.tw + 3) >> 2;
   c.n4  = c.tw4 * c.th;
-  c.mT4 = 0xffffffffu / (unsigned)c.tw4 + 1u;
+  c.mT4 = (unsigned)(AL4 ? d2.x : d2.y);  // 0xffffffff / tw4 + 1, from the host
+  c.mIw = (unsigned)d2.z;
   c.valid = true;
   return c;
 }
@@ -441,7 +443,7 @@ __global__ __launch_bounds__(kFastThreads, TS <= 52 ? 8 : 5) void k_fast_cells(B
       continue;
     }
     const int iw = cur.iw, ih = cur.ih;
-    const unsigned   mIw = iw == 1 ? 0u : 0xffffffffu / (unsigned)iw + 1u;  // interior-width divider for idx -> (row, col)
+    const unsigned   mIw = cur.mIw;  // interior-width divider for idx -> (row, col)
     const int        ox3 = 3 + cur.ox;  // LDS column of interior column 0
     // registers -> LDS (TS is a multiple of 4: aligned; spill past tw stays inside the row)
 #pragma unroll
