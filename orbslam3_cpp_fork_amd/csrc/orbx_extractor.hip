@@ -469,7 +469,7 @@ int orbx_extractor::run(const uint8_t* d_imgs, int B, int rows, int cols, size_t
     // tile geometry of this image size: tiles are staged from the aligned column below iniX (up to +3 columns)
     int maxW = 0, maxH = 0;
     for (int l = 0; l < g.nlevels; l++) maxW = std::max(maxW, g.lv[l].wCell), maxH = std::max(maxH, g.lv[l].hCell);
-    const bool    small = maxW + 9 <= 52 && ((maxW + 9 + 3) / 4) * (maxH + 6) <= kFastSmallPre * kFastThreads;
+    const bool    small = maxW + 9 <= 52 && maxH + 6 <= kFastSmallPre * (kFastThreads / 16);  // staging map of the 52-byte stride: 16 lanes x 8 rows per step
     const int     tsSel = small ? 52 : kFastTileMax;
     orbx::FastLds fl;
     fl.tileBytes = alignUp(tsSel * (maxH + 6), 16);

@@ -320,8 +320,8 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 
 constexpr int kFastCellsPerBlock = 1;  // cells walked by one (persistent) workgroup
 constexpr int kFastThreads       = 128;  // workgroup of k_fast_cells
-constexpr int kFastPrefetchMax   = 14;   // tile dwords a thread may hold in flight for the largest tile (20 x 77 dwords)
-constexpr int kFastSmallPre      = 6;    // ... for the 52-byte-stride instantiation (13 x 59 dwords)
+constexpr int kFastPrefetchMax   = 20;   // row steps of the staging map for the largest tile (80 rows, 4 rows per step)
+constexpr int kFastSmallPre      = 8;    // ... for the 52-byte-stride instantiation (up to 64 rows, 8 rows per step)
 
 struct FastCell {
   bool           valid;  // false: padding slot or a cell the reference skips (:782-793) / that has no interior
@@ -375,22 +375,32 @@ __device__ __forceinline__ FastCell fast_decode(const Bufs& b, const FrameGeom& 
 // levels >= 1, and for level 0 when the caller's image is): one aligned 32-bit load per slot, starting at the aligned
 // column below iniX; the up-to-3 extra bytes on either side lie inside the image row (cells end >= 16 px before the
 // row end).  Otherwise byte loads.
-template <bool AL4, int NPRE>
+// Staging map of a tile: thread = (dword column xw, row y0), rows y0, y0 + RPS, ...: no index arithmetic beyond one add per row.
+// XW lanes span a tile row (16 for the 52-byte stride, 32 for the 80-byte one); NPRE = row steps.
+template <int TS>
+struct FastStage {
+  static constexpr int XW  = TS <= 52 ? 16 : 32;
+  static constexpr int RPS = kFastThreads / XW;  // rows per step
+};
+
+template <bool AL4, int NPRE, int TS>
 __device__ __forceinline__ void fast_prefetch(const FastCell& c, int tid, uint32_t (&r)[NPRE]) {
   if (!c.valid) return;
+  const int xw = tid & (FastStage<TS>::XW - 1), y0 = tid / FastStage<TS>::XW;
+  if (xw >= c.tw4) return;
+  const uint8_t* src = c.img + (long long)y0 * c.pitch + xw * 4;
 #pragma unroll
   for (int k = 0; k < NPRE; k++) {
-    const int idx = tid + k * kFastThreads;
-    if (idx < c.n4) {
-      const int      y = div_magic(idx, c.mT4), x = (idx - y * c.tw4) * 4;
-      const uint8_t* src = c.img + (long long)y * c.pitch + x;
+    if (y0 + k * FastStage<TS>::RPS < c.th) {
+      const uint8_t* p = src + (long long)(k * FastStage<TS>::RPS) * c.pitch;
       if (AL4) {
-        r[k] = *reinterpret_cast<const uint32_t*>(src);
+        r[k] = *reinterpret_cast<const uint32_t*>(p);
       } else {
-        uint32_t v = src[0];
-        if (x + 1 < c.tw) v |= (uint32_t)src[1] << 8;
-        if (x + 2 < c.tw) v |= (uint32_t)src[2] << 16;
-        if (x + 3 < c.tw) v |= (uint32_t)src[3] << 24;
+        const int x = xw * 4;
+        uint32_t  v = p[0];
+        if (x + 1 < c.tw) v |= (uint32_t)p[1] << 8;
+        if (x + 2 < c.tw) v |= (uint32_t)p[2] << 16;
+        if (x + 3 < c.tw) v |= (uint32_t)p[3] << 24;
         r[k] = v;
       }
     }
@@ -431,7 +441,7 @@ __global__ __launch_bounds__(kFastThreads, TS <= 52 ? 8 : 5) void k_fast_cells(B
   uint32_t  pre[NPRE];
   int       xoff = 0, yoff = 0, slotOff = 0, nxoff = 0, nyoff = 0, nslotOff = 0;
   FastCell  cur = fast_decode<AL4>(b, g, k0 * 8 + xcd, nslots, f, &xoff, &yoff, &slotOff);
-  fast_prefetch<AL4, NPRE>(cur, tid, pre);
+  fast_prefetch<AL4, NPRE, TS>(cur, tid, pre);
   for (int cc = 0; cc < kFastCellsPerBlock; cc++) {
     FastCell nxt;
     nxt.valid = false, nxt.cell = -1;
@@ -439,25 +449,29 @@ __global__ __launch_bounds__(kFastThreads, TS <= 52 ? 8 : 5) void k_fast_cells(B
     if (!cur.valid) {
       if (cur.cell >= 0 && tid == 0) b.cellCount[(long long)f * g.totalCells + cur.cell] = 0;
       cur = nxt, xoff = nxoff, yoff = nyoff, slotOff = nslotOff;
-      fast_prefetch<AL4, NPRE>(cur, tid, pre);
+      fast_prefetch<AL4, NPRE, TS>(cur, tid, pre);
       continue;
     }
     const int iw = cur.iw, ih = cur.ih;
     const unsigned   mIw = cur.mIw;  // interior-width divider for idx -> (row, col)
     const int        ox3 = 3 + cur.ox;  // LDS column of interior column 0
-    // registers -> LDS (TS is a multiple of 4: aligned; spill past tw stays inside the row)
+    // registers -> LDS (TS is a multiple of 4: aligned; spill past tw stays inside the row), same (column, row) map as the loads
+    {
+      const int xw = tid & (FastStage<TS>::XW - 1), y0 = tid / FastStage<TS>::XW;
+      if (xw < cur.tw4) {
 #pragma unroll
-    for (int k = 0; k < NPRE; k++) {
-      const int idx = tid + k * kFastThreads;
-      if (idx < cur.n4) {
-        const int y = div_magic(idx, cur.mT4), x = (idx - y * cur.tw4) * 4;
-        *reinterpret_cast<uint32_t*>(tile + y * ts + x)  = pre[k];
-        *reinterpret_cast<uint32_t*>(score + y * ts + x) = 0;
+        for (int k = 0; k < NPRE; k++) {
+          const int y = y0 + k * FastStage<TS>::RPS;
+          if (y < cur.th) {
+            *reinterpret_cast<uint32_t*>(tile + y * ts + xw * 4)  = pre[k];
+            *reinterpret_cast<uint32_t*>(score + y * ts + xw * 4) = 0;
+          }
+        }
       }
     }
     if (tid == 0) candCount = 0, kpCount = 0, cnt1 = 0, cnt2 = 0;
     __syncthreads();
-    fast_prefetch<AL4, NPRE>(nxt, tid, pre);  // in flight during the four passes below
+    fast_prefetch<AL4, NPRE, TS>(nxt, tid, pre);  // in flight during the four passes below
     const int npix = iw * ih;
     // Pass 1 -- necessary condition + compaction.  A 9-arc of the 16-pixel circle leaves out 7 contiguous positions, so
     // it contains at least one of every two OPPOSITE positions: a pixel can only score >= lowTh if, for each of the four
