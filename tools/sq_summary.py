@@ -4,7 +4,8 @@ instructions = SQ_INSTS_VALU per wave / SQ_WAVE_CYCLES per wave (both in 4-clock
 one unit) x waves resident per SIMD.  Residency = min(register / LDS occupancy of the kernel, waves the grid puts on a SIMD)."""
 import json, re, sys
 RES = {  # waves per SIMD while the kernel runs (compiler occupancy report; grid-limited where noted)
-    "k_resize_level": 8, "k_fast_cells": 8, "k_blur_levels": 8, "k_orient_describe": 6,
+    "k_resize_level": 8, "k_fast_cells": 7,  # FAST: 15 two-wave workgroups per CU (10 KB of LDS each)
+    "k_blur_levels": 8, "k_orient_describe": 6,
     "k_bf_topk": 4,      # 1020 workgroups of 4 waves on 256 CUs: 16 waves per CU
     "k_octree": 2,       # 2048 one-wave problems on 1024 SIMDs
     "k_group_resolve": 1, "k_blur_edges": 4, "k_layout": 1,
