@@ -8,6 +8,7 @@
 #include <map>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../orbx.h"
@@ -128,6 +129,76 @@ class ORBmatcher {
                                           curOccupied ? curOccupied->data() : nullptr, n2, scaleFactors.data(), (int)scaleFactors.size(), mfNNratio,
                                           bounds[0], bounds[1], bounds[2], bounds[3], TH_HIGH, curOfMp.data(), nullptr);
     if (n <= -2) throw std::runtime_error(std::string("orbm_search_by_projection_map: ") + orbx_last_error());
+    return n;
+  }
+
+  // Array core of SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const std::set<MapPoint*>& sAlreadyFound, th, ORBdist)
+  // (src/ORBmatcher.cc:1910-2036), the relocalisation search: the Frame-to-Frame core on predicted levels.  mpLevel[i] =
+  // PredictScale(dist3D, &CurrentFrame), kfAngle[i] = pKF->mvKeysUn[i].angle, mpValid[i] = MapPoint present, not bad, not in
+  // sAlreadyFound, inside the bounds and the distance range; curOccupied[i2] = (CurrentFrame.mvpMapPoints[i2] != NULL).
+  int SearchByProjectionKeyFrameArrays(const orbx_cv::Mat& mpDesc, const std::vector<orbx_cv::Point2f>& mpUV, const std::vector<int>& mpLevel,
+                                       const std::vector<float>& kfAngle, const std::vector<unsigned char>& mpValid, const orbx_cv::Mat& curDesc,
+                                       const std::vector<orbx_cv::KeyPoint>& curKeysUn, const std::vector<unsigned char>* curOccupied,
+                                       const std::vector<float>& scaleFactors, float th, int ORBdist, const float bounds[4], std::vector<int>& curOfMp) {
+    const int n1 = (int)mpLevel.size(), n2 = (int)curKeysUn.size();
+    curOfMp.assign(n1, -1);
+    std::vector<uint8_t> d1 = pack(mpDesc), d2 = pack(curDesc);
+    int n = orbm_search_by_projection(h_, d1.data(), reinterpret_cast<const float*>(mpUV.data()), nullptr, mpLevel.data(), kfAngle.data(),
+                                      mpValid.empty() ? nullptr : mpValid.data(), n1, d2.data(), reinterpret_cast<const orbx_keypoint_t*>(curKeysUn.data()),
+                                      nullptr, curOccupied ? curOccupied->data() : nullptr, n2, scaleFactors.data(), (int)scaleFactors.size(), th, 0, 0.f,
+                                      bounds[0], bounds[1], bounds[2], bounds[3], ORBdist, mbCheckOrientation ? 1 : 0, curOfMp.data(), nullptr);
+    if (n <= -2) throw std::runtime_error(std::string("orbm_search_by_projection: ") + orbx_last_error());
+    return n;
+  }
+
+  // Array core of the remaining windowed searches (see orbm_search_in_windows in orbx.h):
+  //   SearchByProjection(KeyFrame*, Sim3f&, vpPoints, vpMatched, th, ratioHamming) (src/ORBmatcher.cc:423-538, :540-664):
+  //     claim = true, kfOccupied[idx] = (vpMatched[idx] != NULL), thDist = (int)std::floor(TH_LOW * ratioHamming)
+  //   Fuse(KeyFrame*, vpMapPoints, th, bRight) (:1149-1328): claim = false, invLevelSigma2 = &pKF->mvInvLevelSigma2, thDist = TH_LOW
+  //     (stereo keyframes: mpUR[i] = uv(0) - bf * invz, kfURight = &pKF->mvuRight)
+  //   Fuse(KeyFrame*, Sim3f&, vpPoints, th, vpReplacePoint) (:1330-1452): claim = false, thDist = TH_LOW
+  //   each direction of SearchBySim3 (:1499-1658): claim = false, thDist = TH_HIGH
+  // kfOfMp[i] = the keyframe feature chosen for point i (-1 = none); returns the number of matched points.
+  int SearchInWindowsArrays(const orbx_cv::Mat& mpDesc, const std::vector<orbx_cv::Point2f>& mpUV, const std::vector<float>* mpUR,
+                            const std::vector<int>& mpLevel, const std::vector<unsigned char>& mpValid, const orbx_cv::Mat& kfDesc,
+                            const std::vector<orbx_cv::KeyPoint>& kfKeysUn, const std::vector<float>* kfURight,
+                            const std::vector<unsigned char>* kfOccupied, const std::vector<float>& scaleFactors,
+                            const std::vector<float>* invLevelSigma2, float th, bool claim, int thDist, const float bounds[4], std::vector<int>& kfOfMp) {
+    const int n1 = (int)mpLevel.size(), n2 = (int)kfKeysUn.size();
+    kfOfMp.assign(n1, -1);
+    std::vector<uint8_t> d1 = pack(mpDesc), d2 = pack(kfDesc);
+    int n = orbm_search_in_windows(h_, d1.data(), reinterpret_cast<const float*>(mpUV.data()), mpUR ? mpUR->data() : nullptr, mpLevel.data(),
+                                   mpValid.empty() ? nullptr : mpValid.data(), n1, d2.data(), reinterpret_cast<const orbx_keypoint_t*>(kfKeysUn.data()),
+                                   kfURight ? kfURight->data() : nullptr, kfOccupied ? kfOccupied->data() : nullptr, n2, scaleFactors.data(),
+                                   invLevelSigma2 ? invLevelSigma2->data() : nullptr, (int)scaleFactors.size(), th, claim ? 1 : 0, bounds[0], bounds[1],
+                                   bounds[2], bounds[3], thDist, kfOfMp.data());
+    if (n <= -2) throw std::runtime_error(std::string("orbm_search_in_windows: ") + orbx_last_error());
+    return n;
+  }
+
+  // Array core of SearchForTriangulation(pKF1, pKF2, vMatchedPairs, bOnlyStereo, bCoarse) (src/ORBmatcher.cc:916-1147) for keyframes of one
+  // pinhole camera.  The common nodes of the two FeatureVectors are flattened by the caller exactly as for SearchByBoW (qOff / qIdx / tOff /
+  // tIdx); hasMp1 / hasMp2[i] = pKF->GetMapPoint(i) != NULL; stereo1 / stereo2[i] = mvuRight[i] >= 0 (NULL = monocular); F12 = K1^-T [t12]x R12
+  // K2^-1 (row major) and ep as the reference computes them.  vMatchedPairs comes back in ascending first index.
+  int SearchForTriangulationArrays(const orbx_cv::Mat& desc1, const std::vector<orbx_cv::KeyPoint>& keysUn1, const std::vector<unsigned char>& hasMp1,
+                                   const std::vector<unsigned char>* stereo1, const orbx_cv::Mat& desc2, const std::vector<orbx_cv::KeyPoint>& keysUn2,
+                                   const std::vector<unsigned char>& hasMp2, const std::vector<unsigned char>* stereo2, const std::vector<int>& qOff,
+                                   const std::vector<int>& qIdx, const std::vector<int>& tOff, const std::vector<int>& tIdx, const float F12[9],
+                                   const float ep[2], const std::vector<float>& scaleFactors, const std::vector<float>& levelSigma2, bool bOnlyStereo,
+                                   bool bCoarse, std::vector<std::pair<std::size_t, std::size_t> >& vMatchedPairs) {
+    const int n1 = (int)keysUn1.size(), n2 = (int)keysUn2.size();
+    std::vector<uint8_t> d1 = pack(desc1), d2 = pack(desc2);
+    std::vector<int>     m12(n1 + 1, -1);
+    int n = orbm_search_for_triangulation(h_, d1.data(), reinterpret_cast<const orbx_keypoint_t*>(keysUn1.data()), hasMp1.empty() ? nullptr : hasMp1.data(),
+                                          stereo1 ? stereo1->data() : nullptr, n1, d2.data(), reinterpret_cast<const orbx_keypoint_t*>(keysUn2.data()),
+                                          hasMp2.empty() ? nullptr : hasMp2.data(), stereo2 ? stereo2->data() : nullptr, n2, (int)qOff.size() - 1, qOff.data(),
+                                          qIdx.data(), tOff.data(), tIdx.data(), F12, ep, scaleFactors.data(), levelSigma2.data(), (int)scaleFactors.size(),
+                                          bOnlyStereo ? 1 : 0, bCoarse ? 1 : 0, TH_LOW, mbCheckOrientation ? 1 : 0, m12.data());
+    if (n <= -2) throw std::runtime_error(std::string("orbm_search_for_triangulation: ") + orbx_last_error());
+    vMatchedPairs.clear();
+    vMatchedPairs.reserve(n);
+    for (int i = 0; i < n1; i++)
+      if (m12[i] >= 0) vMatchedPairs.push_back(std::make_pair((std::size_t)i, (std::size_t)m12[i]));
     return n;
   }
 

@@ -221,6 +221,46 @@ int orbm_search_by_projection_map(orbm_t* h, const uint8_t* mp_desc, const float
                                   const float* scale_factors, int nlevels, float ratio, float min_x, float max_x, float min_y, float max_y,
                                   int th_dist, int* cur_of_mp, int* mp_of_cur);
 
+/* The windowed best-candidate search of the remaining projection matchers, on arrays:
+ *   ORBmatcher::SearchByProjection(KeyFrame*, Sophus::Sim3f&, vpPoints, vpMatched, th, ratioHamming) (src/ORBmatcher.cc:423-538; :540-664
+ *     is the same search) -- claim = 1, t_occupied[idx] = (vpMatched[idx] != NULL), th_dist = floor(TH_LOW * ratioHamming);
+ *   ORBmatcher::Fuse(KeyFrame*, vpMapPoints, th, bRight) (:1149-1328) -- claim = 0, inv_level_sigma2 = mvInvLevelSigma2 (chi-square gate 5.99,
+ *     or 7.8 on the three-term error where t_u_right[idx] >= 0, q_ur = uv(0) - bf * invz), th_dist = TH_LOW;
+ *   ORBmatcher::Fuse(KeyFrame*, Sim3f&, vpPoints, th, vpReplacePoint) (:1330-1452) -- claim = 0, no gate, th_dist = TH_LOW;
+ *   each direction of ORBmatcher::SearchBySim3 (:1499-1577, :1580-1658) -- claim = 0, no gate, th_dist = TH_HIGH.
+ * (SearchByProjection(Frame&, KeyFrame*, sAlreadyFound, th, ORBdist), :1910-2036, is orbm_search_by_projection with dir = 0,
+ * last_octave = the predicted level, last_angle = pKF->mvKeysUn[i].angle and th_dist = ORBdist.)
+ * The loop heads (bad / already found points, depth, IsInImage, distance invariance, viewing angle, PredictScale) are the caller's:
+ * q_valid[i] (NULL = all) says whether point i reaches the search, q_uv its projection, q_level the predicted level, q_desc =
+ * MapPoint::GetDescriptor().  Window = KeyFrame::GetFeaturesInArea(u, v, th * scale_factors[level]) (src/KeyFrame.cc:780-838) over the
+ * 64 x 48 grid on [min_x, max_x] x [min_y, max_y]; keypoints on levels [level - 1, level]; first minimum in scan order; accepted when
+ * <= th_dist.  claim = 1 skips occupied features and closes a matched feature to later points; claim = 0 lets every point search on
+ * its own (the map updates that follow -- Replace / AddObservation -- stay with the caller, replayed in point order).
+ * t_of_q[n1] = matched feature or -1; returns the number of matched points.  Host pointers, synchronous. */
+int orbm_search_in_windows(orbm_t* h, const uint8_t* q_desc, const float* q_uv, const float* q_ur, const int* q_level, const uint8_t* q_valid, int n1,
+                           const uint8_t* t_desc, const orbx_keypoint_t* t_kp, const float* t_u_right, const uint8_t* t_occupied, int n2,
+                           const float* scale_factors, const float* inv_level_sigma2, int nlevels, float th, int claim, float min_x, float max_x,
+                           float min_y, float max_y, int th_dist, int* t_of_q);
+
+/* ORBmatcher::SearchForTriangulation(pKF1, pKF2, vMatchedPairs, bOnlyStereo, bCoarse) (src/ORBmatcher.cc:916-1147)
+ * for two keyframes of one pinhole camera (mpCamera2 == NULL, NLeft == -1), over the vocabulary nodes both FeatureVectors hold,
+ * flattened as for orbm_match_groups: group g pairs KF1's features q_idx[q_off[g] .. q_off[g+1]) with KF2's t_idx[t_off[g] ..).
+ * mp1 / mp2[i] = the feature already has a MapPoint (skipped, :980-984, :1007-1011); stereo1 / stereo2[i] = mvuRight[i] >= 0 (NULL =
+ * monocular); F12 = K1^-T [t12]x R12 K2^-1, row major, exactly the matrix Pinhole::epipolarConstrain forms
+ * (src/CameraModels/Pinhole.cpp:152-156); ep = pKF2->mpCamera->project(T2w * Cw) (:931-934); level_sigma2 = mvLevelSigma2;
+ * th_low = TH_LOW; coarse = bCoarse (skips the epipolar test; F12 / level_sigma2 may then be NULL).  Per KF1 feature: the candidate
+ * with the smallest distance <= th_low that is not within 100 * scale[octave] (squared pixels) of the epipole (monocular pairs) and
+ * lies within 3.84 * sigma2 of the epipolar line, the last of equals in list order; then the rotation histogram (:1112-1129).
+ * The reference never sets vbMatched2, so several KF1 features may receive the same KF2 feature -- reproduced.
+ * matches12[n1] = KF2 feature or -1 (vMatchedPairs = the pairs (i, matches12[i]) in ascending i); returns nmatches.
+ * KannalaBrandt8 / two-camera rigs use a triangulation-based test (src/CameraModels/KannalaBrandt8.cpp) and stay with the caller
+ * unless bCoarse.  Host pointers, synchronous. */
+int orbm_search_for_triangulation(orbm_t* h, const uint8_t* d1, const orbx_keypoint_t* kp1, const uint8_t* mp1, const uint8_t* stereo1, int n1,
+                                  const uint8_t* d2, const orbx_keypoint_t* kp2, const uint8_t* mp2, const uint8_t* stereo2, int n2, int ngroups,
+                                  const int* q_off, const int* q_idx, const int* t_off, const int* t_idx, const float F12[9], const float ep[2],
+                                  const float* scale_factors, const float* level_sigma2, int nlevels, int only_stereo, int coarse, int th_low,
+                                  int check_ori, int* matches12);
+
 /* Frame::AssignFeaturesToGrid (src/Frame.cc:524-553) for every frame of an extraction batch, on the device: the (undistorted)
  * keypoints that fall inside the 64 x 48 grid over [min_x, max_x] x [min_y, max_y], in the scan order of GetFeaturesInArea
  * (cells (ix, iy) ascending, feature index ascending inside a cell).  Frame f writes d_g_idx / d_g_cx / d_g_cy at [f * cap ..]

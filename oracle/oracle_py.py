@@ -319,6 +319,42 @@ def search_by_projection_map(mp_desc, mp_uv, mp_proj_xr, mp_level, mp_radius, mp
     return n, com, moc
 
 
+def search_in_windows(q_desc, q_uv, q_ur, q_level, q_valid, t_desc, t_kp, t_u_right, t_occupied, scale_factors, inv_level_sigma2, th, claim, bounds, th_dist):
+    """Windowed best-candidate search of SearchByProjection(KeyFrame, Sim3, ...) / Fuse / SearchBySim3 at array level (see orb_oracle.h)."""
+    q_desc = np.ascontiguousarray(q_desc, np.uint8)
+    t_desc = np.ascontiguousarray(t_desc, np.uint8)
+    t_kp = np.ascontiguousarray(t_kp, KP_DTYPE)
+    n1, n2 = len(q_desc), len(t_desc)
+    uv = np.ascontiguousarray(q_uv, np.float32).reshape(-1, 2)
+    qr, lv = _opt(q_ur, np.float32), np.ascontiguousarray(q_level, np.int32)
+    va, ur, occ = _opt(q_valid, np.uint8), _opt(t_u_right, np.float32), _opt(t_occupied, np.uint8)
+    sf, s2 = np.ascontiguousarray(scale_factors, np.float32), _opt(inv_level_sigma2, np.float32)
+    toq = np.zeros(n1, np.int32)
+    L = lib()
+    L.orao_search_in_windows.argtypes = [C.c_void_p] * 5 + [C.c_int] + [C.c_void_p] * 4 + [C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_int] + [C.c_float] * 4 + [C.c_int, C.c_void_p]
+    n = L.orao_search_in_windows(_p(q_desc), _p(uv), _p(qr), _p(lv), _p(va), n1, _p(t_desc), _p(t_kp), _p(ur), _p(occ), n2, _p(sf), _p(s2), float(th), int(claim),
+                                 *[float(b) for b in bounds], int(th_dist), _p(toq))
+    return n, toq
+
+
+def search_for_triangulation(d1, kp1, mp1, stereo1, d2, kp2, mp2, stereo2, groups, F12, ep, scale_factors, level_sigma2, only_stereo=False, coarse=False,
+                             th_low=50, check_ori=True):
+    """ORBmatcher::SearchForTriangulation at array level (see orb_oracle.h); groups = (q_off, q_idx, t_off, t_idx)."""
+    d1, d2 = np.ascontiguousarray(d1, np.uint8), np.ascontiguousarray(d2, np.uint8)
+    kp1, kp2 = np.ascontiguousarray(kp1, KP_DTYPE), np.ascontiguousarray(kp2, KP_DTYPE)
+    qo, qi, to, ti = (np.ascontiguousarray(a, np.int32) for a in groups)
+    m1, s1, m2, s2 = _opt(mp1, np.uint8), _opt(stereo1, np.uint8), _opt(mp2, np.uint8), _opt(stereo2, np.uint8)
+    F = np.ascontiguousarray(F12, np.float32).reshape(9)
+    e = np.ascontiguousarray(ep, np.float32).reshape(2)
+    sf, sg = np.ascontiguousarray(scale_factors, np.float32), np.ascontiguousarray(level_sigma2, np.float32)
+    m12 = np.zeros(len(kp1), np.int32)
+    L = lib()
+    L.orao_search_for_triangulation.argtypes = [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 4 + [C.c_int, C.c_int] + [C.c_void_p] * 8 + [C.c_int] * 4 + [C.c_void_p]
+    n = L.orao_search_for_triangulation(_p(d1), _p(kp1), _p(m1), _p(s1), len(kp1), _p(d2), _p(kp2), _p(m2), _p(s2), len(kp2), len(qo) - 1, _p(qo), _p(qi), _p(to),
+                                        _p(ti), _p(F), _p(e), _p(sf), _p(sg), int(only_stereo), int(coarse), int(th_low), int(check_ori), _p(m12))
+    return n, m12
+
+
 def undistort_keypoints(kps, K, dist):
     """Frame::UndistortKeyPoints: K = (fx, fy, cx, cy), dist = (k1, k2, p1, p2[, k3])."""
     kps = np.ascontiguousarray(kps, KP_DTYPE)

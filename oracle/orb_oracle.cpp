@@ -1442,6 +1442,150 @@ int orao_search_by_projection(const uint8_t* last_desc, const float* last_uv, co
   return nmatches;
 }
 
+// The best-candidate search that ORBmatcher::SearchByProjection(KeyFrame*, Sim3f&, vpPoints, vpMatched, th, ratioHamming)
+// (src/ORBmatcher.cc:423-538; :540-664 runs the same loop and also records the source keyframe), both ORBmatcher::Fuse overloads
+// (:1149-1328 with the reprojection gate, :1330-1452 without) and each direction of ORBmatcher::SearchBySim3 (:1499-1577,
+// :1580-1658) have in common, at array level.  The loop heads (isBad, already found, depth, IsInImage, distance invariance,
+// viewing angle, PredictScale) are the caller's: q_valid[i] says whether point i reaches the window search, q_uv carries the
+// projection, q_level the predicted level, q_ur (stereo Fuse only) uv(0) - bf * invz.
+//   window   KeyFrame::GetFeaturesInArea(u, v, th * mvScaleFactors[level]) (src/KeyFrame.cc:780-838), then only keypoints on
+//            levels [level - 1, level] (:497-499, :1251-1253, :1417-1419, :1544-1546)
+//   gate     inv_level_sigma2 != NULL (Fuse :1255-1283): e2 * mvInvLevelSigma2[kpLevel] > 5.99 rejects (three-term error
+//            and 7.8 when t_u_right[idx] >= 0)
+//   claim    1: features with t_occupied set are skipped and a match closes its feature to later points (vpMatched, :489-491,
+//            :507-510); 0: every point searches on its own (Fuse, SearchBySim3)
+//   accept   bestDist <= th_dist (first minimum in scan order)
+// t_of_q[n1] = matched feature or -1; returns the number of matched points.
+int orao_search_in_windows(const uint8_t* q_desc, const float* q_uv, const float* q_ur, const int* q_level, const uint8_t* q_valid, int n1,
+                           const uint8_t* t_desc, const orao_keypoint_t* t_kp, const float* t_u_right, const uint8_t* t_occupied, int n2,
+                           const float* mvScaleFactors, const float* mvInvLevelSigma2, float th, int claim, float mnMinX, float mnMaxX,
+                           float mnMinY, float mnMaxY, int th_dist, int* t_of_q) {
+  const int   GRID_COLS = 64, GRID_ROWS = 48;
+  const float wInv = static_cast<float>(GRID_COLS) / (mnMaxX - mnMinX);
+  const float hInv = static_cast<float>(GRID_ROWS) / (mnMaxY - mnMinY);
+  std::vector<std::vector<int>> cells((size_t)GRID_COLS * GRID_ROWS);  // the Frame's grid, copied by the KeyFrame (src/Frame.cc:524-553)
+  for (int i = 0; i < n2; i++) {
+    const int gx = (int)std::round((t_kp[i].x - mnMinX) * wInv), gy = (int)std::round((t_kp[i].y - mnMinY) * hInv);
+    if (gx < 0 || gx >= GRID_COLS || gy < 0 || gy >= GRID_ROWS) continue;
+    cells[(size_t)gx * GRID_ROWS + gy].push_back(i);
+  }
+  std::vector<uint8_t> taken(n2, 0);
+  if (claim && t_occupied)
+    for (int i = 0; i < n2; i++) taken[i] = t_occupied[i] ? 1 : 0;
+  int found = 0;
+  for (int iMP = 0; iMP < n1; iMP++) {
+    t_of_q[iMP] = -1;
+    if (q_valid && !q_valid[iMP]) continue;
+    const float u = q_uv[2 * iMP], v = q_uv[2 * iMP + 1];
+    const int   nPredictedLevel = q_level[iMP];
+    const float radius          = th * mvScaleFactors[nPredictedLevel];
+    const int   cx0 = std::max(0, (int)std::floor((u - mnMinX - radius) * wInv));
+    if (cx0 >= GRID_COLS) continue;
+    const int cx1 = std::min(GRID_COLS - 1, (int)std::ceil((u - mnMinX + radius) * wInv));
+    if (cx1 < 0) continue;
+    const int cy0 = std::max(0, (int)std::floor((v - mnMinY - radius) * hInv));
+    if (cy0 >= GRID_ROWS) continue;
+    const int cy1 = std::min(GRID_ROWS - 1, (int)std::ceil((v - mnMinY + radius) * hInv));
+    if (cy1 < 0) continue;
+    int bestDist = 256, bestIdx = -1;
+    for (int gx = cx0; gx <= cx1; gx++)
+      for (int gy = cy0; gy <= cy1; gy++)
+        for (int idx : cells[(size_t)gx * GRID_ROWS + gy]) {
+          const orao_keypoint_t& kp = t_kp[idx];
+          if (!(std::fabs(kp.x - u) < radius && std::fabs(kp.y - v) < radius)) continue;
+          if (claim && taken[idx]) continue;
+          const int kpLevel = kp.octave;
+          if (kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel) continue;
+          if (mvInvLevelSigma2) {
+            const float ex = u - kp.x, ey = v - kp.y;
+            if (t_u_right && t_u_right[idx] >= 0) {
+              const float er = q_ur[iMP] - t_u_right[idx];
+              const float e2 = ex * ex + ey * ey + er * er;
+              if (e2 * mvInvLevelSigma2[kpLevel] > 7.8) continue;
+            } else {
+              const float e2 = ex * ex + ey * ey;
+              if (e2 * mvInvLevelSigma2[kpLevel] > 5.99) continue;
+            }
+          }
+          const int dist = orao_hamming(q_desc + (size_t)iMP * 32, t_desc + (size_t)idx * 32);
+          if (dist < bestDist) bestDist = dist, bestIdx = idx;
+        }
+    if (bestDist <= th_dist) {
+      t_of_q[iMP] = bestIdx;
+      if (claim) taken[bestIdx] = 1;
+      found++;
+    }
+  }
+  return found;
+}
+
+// ORBmatcher::SearchForTriangulation(pKF1, pKF2, vMatchedPairs, bOnlyStereo, bCoarse) (src/ORBmatcher.cc:916-1147) for two
+// keyframes of one pinhole camera (mpCamera2 == NULL, NLeft == -1), at array level.  Group g = a vocabulary node both
+// FeatureVectors hold (the merge walk :973-1110): features q_idx[q_off[g] ..) of KF1 meet t_idx[t_off[g] ..) of KF2.
+// mp1 / mp2 = the feature already has a MapPoint (:980-984, :1007-1011); stereo1 / stereo2 = mvuRight >= 0; F12 (row major) =
+// K1^-T [t12]x R12 K2^-1 as Pinhole::epipolarConstrain builds it (src/CameraModels/Pinhole.cpp:152-156); ep = projection of
+// KF1's centre into KF2 (:931-934).  vbMatched2 is never set in the reference, so the features of KF1 do not interact.
+int orao_search_for_triangulation(const uint8_t* d1, const orao_keypoint_t* kp1, const uint8_t* mp1, const uint8_t* stereo1, int n1,
+                                  const uint8_t* d2, const orao_keypoint_t* kp2, const uint8_t* mp2, const uint8_t* stereo2, int n2, int ngroups,
+                                  const int* q_off, const int* q_idx, const int* t_off, const int* t_idx, const float* F12, const float* ep,
+                                  const float* mvScaleFactors, const float* mvLevelSigma2, int bOnlyStereo, int bCoarse, int th_low,
+                                  int check_ori, int* vMatches12) {
+  int              nmatches = 0;
+  std::vector<int> rotHist[HISTO_LENGTH];
+  for (int i = 0; i < n1; i++) vMatches12[i] = -1;
+  for (int g = 0; g < ngroups; g++) {
+    for (int e1 = q_off[g]; e1 < q_off[g + 1]; e1++) {
+      const int idx1 = q_idx[e1];
+      if (mp1 && mp1[idx1]) continue;
+      const bool bStereo1 = stereo1 && stereo1[idx1];
+      if (bOnlyStereo && !bStereo1) continue;
+      const orao_keypoint_t& k1 = kp1[idx1];
+      int bestDist = th_low, bestIdx2 = -1;
+      for (int e2 = t_off[g]; e2 < t_off[g + 1]; e2++) {
+        const int idx2 = t_idx[e2];
+        if (mp2 && mp2[idx2]) continue;
+        const bool bStereo2 = stereo2 && stereo2[idx2];
+        if (bOnlyStereo && !bStereo2) continue;
+        const int dist = orao_hamming(d1 + (size_t)idx1 * 32, d2 + (size_t)idx2 * 32);
+        if (dist > th_low || dist > bestDist) continue;
+        const orao_keypoint_t& k2 = kp2[idx2];
+        if (!bStereo1 && !bStereo2) {  // too close to the epipole (:1031-1037)
+          const float distex = ep[0] - k2.x, distey = ep[1] - k2.y;
+          if (distex * distex + distey * distey < 100 * mvScaleFactors[k2.octave]) continue;
+        }
+        bool pass = bCoarse != 0;
+        if (!pass) {  // Pinhole::epipolarConstrain (src/CameraModels/Pinhole.cpp:158-173), unc = mvLevelSigma2[kp2.octave]
+          const float a = k1.x * F12[0] + k1.y * F12[3] + F12[6];
+          const float b = k1.x * F12[1] + k1.y * F12[4] + F12[7];
+          const float c = k1.x * F12[2] + k1.y * F12[5] + F12[8];
+          const float num = a * k2.x + b * k2.y + c;
+          const float den = a * a + b * b;
+          if (den != 0) {
+            const float dsqr = num * num / den;
+            pass             = dsqr < 3.84 * mvLevelSigma2[k2.octave];
+          }
+        }
+        if (pass) bestIdx2 = idx2, bestDist = dist;
+      }
+      if (bestIdx2 >= 0) {
+        vMatches12[idx1] = bestIdx2;
+        nmatches++;
+        if (check_ori) rotHist[rotBin(k1.angle, kp2[bestIdx2].angle)].push_back(idx1);
+      }
+    }
+  }
+  if (check_ori) {  // :1112-1129
+    int ind1 = -1, ind2 = -1, ind3 = -1, counts[HISTO_LENGTH];
+    for (int i = 0; i < HISTO_LENGTH; i++) counts[i] = (int)rotHist[i].size();
+    orao_three_maxima(counts, HISTO_LENGTH, &ind1, &ind2, &ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i == ind1 || i == ind2 || i == ind3) continue;
+      for (int idx1 : rotHist[i]) vMatches12[idx1] = -1, nmatches--;
+    }
+  }
+  return nmatches;
+}
+
 // ------------------------------------------------------------------------------------------------
 // N2: DBoW2 TemplatedVocabulary<FORB::TDescriptor, FORB>::transform (TF_IDF weighting, L1_NORM scoring)
 // ------------------------------------------------------------------------------------------------

@@ -134,6 +134,27 @@ int orao_search_by_projection_map(const uint8_t* mp_desc, const float* mp_uv, co
                                   const float* scale_factors, float ratio, float min_x, float max_x, float min_y, float max_y, int th_dist,
                                   int* cur_of_mp, int* mp_of_cur);
 
+/* The windowed best-candidate search shared by SearchByProjection(KeyFrame*, Sim3f&, ...) (src/ORBmatcher.cc:423-538, :540-664),
+ * Fuse (:1149-1328, :1330-1452) and the two directions of SearchBySim3 (:1499-1658): KeyFrame::GetFeaturesInArea
+ * (src/KeyFrame.cc:780-838) with radius th * scale[q_level], keypoint levels [q_level - 1, q_level], first minimum, accepted
+ * when <= th_dist.  inv_level_sigma2 != NULL adds Fuse's reprojection gate (5.99; 7.8 with t_u_right[idx] >= 0 and q_ur);
+ * claim = 1 skips t_occupied features and closes a matched feature to later points (vpMatched), claim = 0 searches every
+ * point on its own.  t_of_q[n1] out; returns the number of matched points. */
+int orao_search_in_windows(const uint8_t* q_desc, const float* q_uv, const float* q_ur, const int* q_level, const uint8_t* q_valid, int n1,
+                           const uint8_t* t_desc, const orao_keypoint_t* t_kp, const float* t_u_right, const uint8_t* t_occupied, int n2,
+                           const float* scale_factors, const float* inv_level_sigma2, float th, int claim, float min_x, float max_x,
+                           float min_y, float max_y, int th_dist, int* t_of_q);
+
+/* ORBmatcher::SearchForTriangulation (src/ORBmatcher.cc:916-1147), keyframes of one pinhole camera (mpCamera2 == NULL), over the
+ * flattened common nodes of the two FeatureVectors (as orao_match_groups).  mp1 / mp2 = feature already has a MapPoint, stereo1 /
+ * stereo2 = mvuRight >= 0 (NULL = none); F12[9] row major and ep[2] as the reference computes them (:931-934,
+ * src/CameraModels/Pinhole.cpp:152-156); level_sigma2 = mvLevelSigma2.  vMatches12[n1] out (-1 = none); returns nmatches. */
+int orao_search_for_triangulation(const uint8_t* d1, const orao_keypoint_t* kp1, const uint8_t* mp1, const uint8_t* stereo1, int n1,
+                                  const uint8_t* d2, const orao_keypoint_t* kp2, const uint8_t* mp2, const uint8_t* stereo2, int n2, int ngroups,
+                                  const int* q_off, const int* q_idx, const int* t_off, const int* t_idx, const float* F12, const float* ep,
+                                  const float* scale_factors, const float* level_sigma2, int only_stereo, int coarse, int th_low,
+                                  int check_ori, int* matches12);
+
 /* Frame::UndistortKeyPoints (src/Frame.cc:886-913): cv::undistortPoints(mat, mat, K, mDistCoef, cv::Mat(), mK) on the keypoint
  * coordinates (OpenCV cvUndistortPointsInternal, 5 iterations, doubles); K = (fx, fy, cx, cy) floats, dist = k1 k2 p1 p2 [k3]
  * floats (ndist = 4 or 5).  dist[0] == 0 copies the keypoints (:887-890).  The other KeyPoint fields are copied. */

@@ -838,6 +838,9 @@ struct ProjArgs {
   const float* radius1;
   float        ratio;
   int          dstar;  // mode 1: a second-best at distance >= dstar can never veto a best <= thDist
+  // mode 2 = the point-by-point search of Fuse / SearchBySim3 (src/ORBmatcher.cc:1149-1452, :1499-1658): levels [predicted - 1, predicted],
+  // no claims, `invz` carries uv(0) - bf / z; invSigma2 != NULL adds Fuse's reprojection gate (:1255-1283)
+  const float* invSigma2;
 };
 
 __device__ __forceinline__ ProjArgs proj_view(const ProjArgs& a, int p) {
@@ -876,7 +879,9 @@ __device__ __forceinline__ ProjQuery proj_query(const ProjArgs& a, int i) {
   if (a.mode == 1) {
     q.r    = a.radius1[i] * a.sf[o];  // r * F.mvScaleFactors[nPredictedLevel] (:70-76)
     q.minL = o - 1, q.maxL = o;
-  } else if (a.dir == 1)
+  } else if (a.mode == 2 || a.dir == 3)
+    q.minL = o - 1, q.maxL = o;  // kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel -> continue (:497-499, :1251-1253)
+  else if (a.dir == 1)
     q.minL = o, q.maxL = -1;  // bForward: GetFeaturesInArea(u, v, radius, nLastOctave)
   else if (a.dir == 2)
     q.minL = 0, q.maxL = o;   // bBackward
@@ -904,6 +909,20 @@ __device__ __forceinline__ int proj_candidate(const ProjArgs& a, const ProjQuery
   }
   const float dx = kp.x - q.u, dy = kp.y - q.v;
   if (!(fabsf(dx) < q.r && fabsf(dy) < q.r)) return -1;
+  if (a.mode == 2) {
+    if (a.invSigma2) {  // Fuse (:1255-1283): chi-square gate on the reprojection error at the keypoint's level
+      const float ex = q.u - kp.x, ey = q.v - kp.y;
+      if (a.uRight && a.uRight[i2] >= 0) {
+        const float er = q.invz - a.uRight[i2];
+        const float e2 = ex * ex + ey * ey + er * er;
+        if ((double)(e2 * a.invSigma2[kp.octave]) > 7.8) return -1;
+      } else {
+        const float e2 = ex * ex + ey * ey;
+        if ((double)(e2 * a.invSigma2[kp.octave]) > 5.99) return -1;
+      }
+    }
+    return i2;
+  }
   if (a.uRight && a.uRight[i2] > 0) {  // :1770-1776 / :101-106
     const float ur = a.mode == 1 ? q.invz : q.u - a.mbf * q.invz;  // mode 1: pMP->mTrackProjXR
     const float er = fabsf(ur - a.uRight[i2]);
@@ -934,6 +953,24 @@ __global__ __launch_bounds__(256) void k_proj_topk(ProjArgs a0) {
     for (int j = 0; j < kTopK; j++) a.topk[(size_t)i1 * kTopK + j] = out[j];
     a.nvalid[i1] = nv;
   }
+}
+
+// mode 2: every point keeps the head of its list (first minimum in scan order) when that is within thDist -- the points do not
+// interact (Fuse :1289-1308, SearchBySim3 :1571-1573)
+__global__ __launch_bounds__(256) void k_proj_take_best(ProjArgs a) {
+  __shared__ int total;
+  if (threadIdx.x == 0) total = 0;
+  __syncthreads();
+  int mine = 0;
+  for (int i = threadIdx.x; i < a.n1; i += 256) {
+    const uint32_t key = a.topk[(size_t)i * kTopK];
+    const bool     ok  = key != kEmpty && (int)(key >> kPosBits) <= a.thDist;
+    a.m12[i]           = ok ? a.g_idx[key & kPosMask] : -1;
+    mine += ok;
+  }
+  if (mine) atomicAdd(&total, mine);
+  __syncthreads();
+  if (threadIdx.x == 0) *a.nmatches = total;
 }
 
 // Frame::AssignFeaturesToGrid / PosInGrid (src/Frame.cc:524-553, 867-877) for every frame of a batch: the features that fall in
@@ -1593,7 +1630,7 @@ int orbm_match_window(orbm_t* h, const uint8_t* d1, const orbx_keypoint_t* kp1, 
 }
 
 // ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, th, bMono) at array level (see include/orbx.h)
-static int proj_single(orbm_t* h, int mode, const float* radius1, float ratio, const uint8_t* last_desc, const float* last_uv, const float* last_invz,
+static int proj_single(orbm_t* h, int mode, const float* inv_sigma2, const float* radius1, float ratio, const uint8_t* last_desc, const float* last_uv, const float* last_invz,
                        const int* last_octave, const float* last_angle, const uint8_t* last_valid, int n1, const uint8_t* cur_desc,
                        const orbx_keypoint_t* cur_kp, const float* cur_u_right, const uint8_t* cur_occupied, int n2,
                        const float* scale_factors, int nlevels, float th, int dir, float mbf, float min_x, float max_x, float min_y,
@@ -1608,7 +1645,7 @@ int orbm_search_by_projection(orbm_t* h, const uint8_t* last_desc, const float* 
     set_err("orbm_search_by_projection: bad arguments");
     return -2;
   }
-  return proj_single(h, 0, nullptr, 0.f, last_desc, last_uv, last_invz, last_octave, last_angle, last_valid, n1, cur_desc, cur_kp, cur_u_right,
+  return proj_single(h, 0, nullptr, nullptr, 0.f, last_desc, last_uv, last_invz, last_octave, last_angle, last_valid, n1, cur_desc, cur_kp, cur_u_right,
                      cur_occupied, n2, scale_factors, nlevels, th, dir, mbf, min_x, max_x, min_y, max_y, th_dist, check_ori, cur_of_last, last_of_cur);
 }
 
@@ -1622,17 +1659,17 @@ int orbm_search_by_projection_map(orbm_t* h, const uint8_t* mp_desc, const float
     set_err("orbm_search_by_projection_map: bad arguments");
     return -2;
   }
-  return proj_single(h, 1, mp_radius, ratio, mp_desc, mp_uv, mp_proj_xr, mp_level, nullptr, mp_valid, n1, cur_desc, cur_kp, cur_u_right, cur_occupied,
+  return proj_single(h, 1, nullptr, mp_radius, ratio, mp_desc, mp_uv, mp_proj_xr, mp_level, nullptr, mp_valid, n1, cur_desc, cur_kp, cur_u_right, cur_occupied,
                      n2, scale_factors, nlevels, 1.0f, 0, 0.f, min_x, max_x, min_y, max_y, th_dist, 0, cur_of_mp, mp_of_cur);
 }
 
-static int proj_single(orbm_t* h, int mode, const float* radius1, float ratio, const uint8_t* last_desc, const float* last_uv, const float* last_invz,
+static int proj_single(orbm_t* h, int mode, const float* inv_sigma2, const float* radius1, float ratio, const uint8_t* last_desc, const float* last_uv, const float* last_invz,
                        const int* last_octave, const float* last_angle, const uint8_t* last_valid, int n1, const uint8_t* cur_desc,
                        const orbx_keypoint_t* cur_kp, const float* cur_u_right, const uint8_t* cur_occupied, int n2,
                        const float* scale_factors, int nlevels, float th, int dir, float mbf, float min_x, float max_x, float min_y,
                        float max_y, int th_dist, int check_ori, int* cur_of_last, int* last_of_cur) {
   if (!h || n1 < 0 || n2 < 0 || !cur_of_last || (n1 > 0 && (!last_desc || !last_uv || !last_octave)) ||
-      (n2 > 0 && (!cur_desc || !cur_kp)) || !scale_factors || nlevels < 1 || nlevels > 64 || dir < 0 || dir > 2 || !(max_x > min_x) ||
+      (n2 > 0 && (!cur_desc || !cur_kp)) || !scale_factors || nlevels < 1 || nlevels > 64 || dir < 0 || dir > 3 || !(max_x > min_x) ||
       !(max_y > min_y) || (cur_u_right && n1 > 0 && !last_invz)) {
     set_err("orbm_search_by_projection: bad arguments");
     return -2;
@@ -1686,6 +1723,7 @@ static int proj_single(orbm_t* h, int mode, const float* radius1, float ratio, c
   a.g_idx = in.put(gidx.data(), ng), a.g_cx = in.put(gcx.data(), ng), a.g_cy = in.put(gcy.data(), ng);
   a.uv = in.put(last_uv, (size_t)2 * n1), a.angle1 = last_angle ? in.put(last_angle, n1) : nullptr, a.invz = last_invz ? in.put(last_invz, n1) : nullptr;
   a.radius1 = radius1 ? in.put(radius1, n1) : nullptr, a.mode = mode, a.ratio = ratio;
+  a.invSigma2 = inv_sigma2 ? in.put(inv_sigma2, nlevels) : nullptr;
   if (mode == 1) {  // a runner-up at distance D vetoes a best d1 <= th only if d1 > ratio * D: none can from the first D with !(th > ratio * D)
     int D = th_dist + 1;
     while (D < 257 && (float)th_dist > ratio * (float)D) D++;
@@ -1699,14 +1737,186 @@ static int proj_single(orbm_t* h, int mode, const float* radius1, float ratio, c
   a.n1 = n1, a.n2 = n2, a.ng = ng, a.th = th, a.mbf = mbf, a.minX = min_x, a.minY = min_y, a.gwInv = gwInv, a.ghInv = ghInv, a.dir = dir;
   a.thDist = th_dist, a.check_ori = check_ori, a.topk = h->topk.p, a.nvalid = h->nvalid.p, a.binOf = h->binOf.p;
   if (n1 > 0) hipLaunchKernelGGL(k_proj_topk, dim3((n1 + 3) / 4), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(k_proj_resolve, dim3(1), dim3(64), 0, s, a);
+  if (mode == 2)
+    hipLaunchKernelGGL(k_proj_take_best, dim3(1), dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL(k_proj_resolve, dim3(1), dim3(64), 0, s, a);
   HIP_TRYM(hipGetLastError());
   HIP_TRYM(hipMemcpyAsync(out.h, out.d, out.off, hipMemcpyDeviceToHost, s));
   HIP_TRYM(hipStreamSynchronize(s));
   const int nm = *out.host_of(a.nmatches);
   if (n1) memcpy(cur_of_last, out.host_of(a.m12), (size_t)n1 * 4);
-  if (n2 && last_of_cur) memcpy(last_of_cur, out.host_of(a.m21), (size_t)n2 * 4);
+  if (n2 && last_of_cur && mode != 2) memcpy(last_of_cur, out.host_of(a.m21), (size_t)n2 * 4);
   return nm;
+}
+
+// the windowed search of SearchByProjection(KeyFrame*, Sim3f&, ...) / Fuse / SearchBySim3 on arrays (include/orbx.h)
+int orbm_search_in_windows(orbm_t* h, const uint8_t* q_desc, const float* q_uv, const float* q_ur, const int* q_level, const uint8_t* q_valid, int n1,
+                           const uint8_t* t_desc, const orbx_keypoint_t* t_kp, const float* t_u_right, const uint8_t* t_occupied, int n2,
+                           const float* scale_factors, const float* inv_level_sigma2, int nlevels, float th, int claim, float min_x, float max_x,
+                           float min_y, float max_y, int th_dist, int* t_of_q) {
+  if ((claim != 0 && claim != 1) || (claim && inv_level_sigma2) || (inv_level_sigma2 && t_u_right && n1 > 0 && !q_ur)) {
+    set_err("orbm_search_in_windows: bad arguments");
+    return -2;
+  }
+  if (claim)  // mode 0 with the [level - 1, level] window: occupied features are skipped, a match closes its feature
+    return proj_single(h, 0, nullptr, nullptr, 0.f, q_desc, q_uv, nullptr, q_level, nullptr, q_valid, n1, t_desc, t_kp, nullptr, t_occupied, n2,
+                       scale_factors, nlevels, th, 3, 0.f, min_x, max_x, min_y, max_y, th_dist, 0, t_of_q, nullptr);
+  return proj_single(h, 2, inv_level_sigma2, nullptr, 0.f, q_desc, q_uv, q_ur, q_level, nullptr, q_valid, n1, t_desc, t_kp,
+                     inv_level_sigma2 ? t_u_right : nullptr, nullptr, n2, scale_factors, nlevels, th, 0, 0.f, min_x, max_x, min_y, max_y, th_dist, 0,
+                     t_of_q, nullptr);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// ORBmatcher::SearchForTriangulation (src/ORBmatcher.cc:916-1147), keyframes of one pinhole camera.  The reference never sets
+// vbMatched2, so every feature of KF1 searches its node's features of KF2 on its own: one wave per list entry, candidates over
+// the lanes, winner = smallest distance among the candidates that pass the gates, the LAST of equals in list order (a candidate
+// at `dist == bestDist` replaces the holder, :1019).
+// ---------------------------------------------------------------------------------------------------------------
+struct TriArgs {
+  const uint8_t *        d1, *d2, *mp1, *mp2, *st1, *st2;
+  const orbx_keypoint_t *kp1, *kp2;
+  const int *            q_idx, *q_grp, *t_off, *t_idx;
+  const float *          sf, *sigma2;
+  float                  F[9], ep[2];
+  int                    n1, nqe, onlyStereo, coarse, th, check_ori;
+  int *                  m12, *binOf, *nmatches;
+};
+
+__global__ __launch_bounds__(256) void k_tri_search(TriArgs a) {
+  const int e = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (e >= a.nqe) return;
+  const int idx1 = a.q_idx[e];
+  if (a.mp1 && a.mp1[idx1]) return;  // :980-984
+  const bool bStereo1 = a.st1 && a.st1[idx1];
+  if (a.onlyStereo && !bStereo1) return;
+  const orbx_keypoint_t k1 = a.kp1[idx1];
+  const uint4           q0 = *reinterpret_cast<const uint4*>(a.d1 + (size_t)idx1 * 32);
+  const uint4           q1 = *reinterpret_cast<const uint4*>(a.d1 + (size_t)idx1 * 32 + 16);
+  // epipolar line of kp1 in the second image (src/CameraModels/Pinhole.cpp:158-161)
+  const float la = k1.x * a.F[0] + k1.y * a.F[3] + a.F[6];
+  const float lb = k1.x * a.F[1] + k1.y * a.F[4] + a.F[7];
+  const float lc = k1.x * a.F[2] + k1.y * a.F[5] + a.F[8];
+  const float den = la * la + lb * lb;
+  const int   g = a.q_grp[e], t0 = a.t_off[g], t1 = a.t_off[g + 1];
+  uint32_t    best = 0xffffffffu;  // distance << 20 | (0xfffff - position in the node's list): the minimum is the reference's winner
+  for (int p = t0 + lane; p < t1; p += 64) {
+    const int idx2 = a.t_idx[p];
+    if (a.mp2 && a.mp2[idx2]) continue;  // :1007-1011
+    const bool bStereo2 = a.st2 && a.st2[idx2];
+    if (a.onlyStereo && !bStereo2) continue;
+    const int dist = hamming256(q0, q1, a.d2 + (size_t)idx2 * 32);
+    if (dist > a.th) continue;  // :1019
+    const orbx_keypoint_t k2 = a.kp2[idx2];
+    if (!bStereo1 && !bStereo2) {  // :1031-1037
+      const float distex = a.ep[0] - k2.x, distey = a.ep[1] - k2.y;
+      if (distex * distex + distey * distey < 100 * a.sf[k2.octave]) continue;
+    }
+    if (!a.coarse) {  // Pinhole::epipolarConstrain (:163-173)
+      const float num = la * k2.x + lb * k2.y + lc;
+      if (den == 0) continue;
+      const float dsqr = num * num / den;
+      if (!((double)dsqr < 3.84 * (double)a.sigma2[k2.octave])) continue;
+    }
+    const uint32_t key = ((uint32_t)dist << 20) | (uint32_t)(0xfffff - (p - t0));
+    best               = min(best, key);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) best = min(best, (uint32_t)__shfl_xor((int)best, o, 64));
+  if (lane == 0 && best != 0xffffffffu) {
+    const int idx2 = a.t_idx[t0 + (0xfffff - (int)(best & 0xfffff))];
+    a.m12[idx1]    = idx2;
+    if (a.check_ori) a.binOf[idx1] = rot_bin(k1.angle, a.kp2[idx2].angle);  // :1085-1098
+  }
+}
+
+// rotation histogram over the matches, three maxima, removal of the other bins (:1112-1129), and the count
+__global__ __launch_bounds__(256) void k_tri_finish(TriArgs a) {
+  __shared__ int hist[kHistoLen];
+  __shared__ int total;
+  const int      tid = threadIdx.x;
+  if (tid < kHistoLen) hist[tid] = 0;
+  if (tid == 0) total = 0;
+  __syncthreads();
+  int mine = 0;
+  for (int i = tid; i < a.n1; i += 256)
+    if (a.m12[i] >= 0) {
+      mine++;
+      if (a.check_ori) atomicAdd(&hist[a.binOf[i]], 1);
+    }
+  if (mine) atomicAdd(&total, mine);
+  __syncthreads();
+  if (a.check_ori) {
+    int i1, i2, i3;
+    three_maxima(hist, kHistoLen, i1, i2, i3);
+    int removed = 0;
+    for (int i = tid; i < a.n1; i += 256)
+      if (a.m12[i] >= 0) {
+        const int b = a.binOf[i];
+        if (b != i1 && b != i2 && b != i3) a.m12[i] = -1, removed++;
+      }
+    if (removed) atomicSub(&total, removed);
+    __syncthreads();
+  }
+  if (tid == 0) *a.nmatches = total;
+}
+
+int orbm_search_for_triangulation(orbm_t* h, const uint8_t* d1, const orbx_keypoint_t* kp1, const uint8_t* mp1, const uint8_t* stereo1, int n1,
+                                  const uint8_t* d2, const orbx_keypoint_t* kp2, const uint8_t* mp2, const uint8_t* stereo2, int n2, int ngroups,
+                                  const int* q_off, const int* q_idx, const int* t_off, const int* t_idx, const float F12[9], const float ep[2],
+                                  const float* scale_factors, const float* level_sigma2, int nlevels, int only_stereo, int coarse, int th_low,
+                                  int check_ori, int* matches12) {
+  if (!h || n1 < 0 || n2 < 0 || ngroups < 0 || !matches12 || (n1 > 0 && (!d1 || !kp1)) || (n2 > 0 && (!d2 || !kp2)) ||
+      (ngroups > 0 && (!q_off || !q_idx || !t_off || !t_idx)) || !ep || !scale_factors || nlevels < 1 || nlevels > 64 || (!coarse && (!F12 || !level_sigma2))) {
+    set_err("orbm_search_for_triangulation: bad arguments");
+    return -2;
+  }
+  const int nqe = ngroups ? q_off[ngroups] : 0, nte = ngroups ? t_off[ngroups] : 0;
+  for (int g = 0; g < ngroups; g++)
+    if (q_off[g] < 0 || t_off[g] < 0 || q_off[g] > q_off[g + 1] || t_off[g] > t_off[g + 1] || t_off[g + 1] - t_off[g] > 0xfffff) {
+      set_err("orbm_search_for_triangulation: offsets must be non-decreasing (at most 2^20 - 1 features under one node)");
+      return -2;
+    }
+  std::vector<int> qgrp(nqe + 1);
+  for (int g = 0; g < ngroups; g++)
+    for (int e = q_off[g]; e < q_off[g + 1]; e++) {
+      if (q_idx[e] < 0 || q_idx[e] >= n1) {
+        set_err("orbm_search_for_triangulation: q_idx out of range");
+        return -2;
+      }
+      qgrp[e] = g;
+    }
+  for (int e = 0; e < nte; e++)
+    if (t_idx[e] < 0 || t_idx[e] >= n2 || kp2[t_idx[e]].octave < 0 || kp2[t_idx[e]].octave >= nlevels) {
+      set_err("orbm_search_for_triangulation: t_idx or a keypoint octave out of range");
+      return -2;
+    }
+  HIP_TRYM(hipSetDevice(h->device));
+  hipStream_t  s       = h->stream;
+  const size_t inBytes = (size_t)(n1 + n2) * (32 + sizeof(orbx_keypoint_t) + 2) + (size_t)(2 * nqe + nte + ngroups + 2) * 4 + 128 * 4 + 20 * 16;
+  if (h->in.reserve(inBytes) || h->out.reserve((size_t)(n1 + 4) * 4 + 64) || h->binOf.ensure(n1 + 1)) return -3;
+  TriArgs a;
+  memset(&a, 0, sizeof(a));
+  Arena& in = h->in;
+  a.d1 = in.put(d1, (size_t)n1 * 32), a.d2 = in.put(d2, (size_t)n2 * 32), a.kp1 = in.put(kp1, n1), a.kp2 = in.put(kp2, n2);
+  a.mp1 = mp1 ? in.put(mp1, n1) : nullptr, a.mp2 = mp2 ? in.put(mp2, n2) : nullptr;
+  a.st1 = stereo1 ? in.put(stereo1, n1) : nullptr, a.st2 = stereo2 ? in.put(stereo2, n2) : nullptr;
+  a.q_idx = in.put(q_idx, nqe), a.q_grp = in.put(qgrp.data(), nqe), a.t_off = in.put(t_off, ngroups + 1), a.t_idx = in.put(t_idx, nte);
+  a.sf = in.put(scale_factors, nlevels), a.sigma2 = level_sigma2 ? in.put(level_sigma2, nlevels) : nullptr;
+  for (int i = 0; i < 9; i++) a.F[i] = F12 ? F12[i] : 0.f;
+  a.ep[0] = ep[0], a.ep[1] = ep[1];
+  HIP_TRYM(hipMemcpyAsync(in.d, in.h, in.off, hipMemcpyHostToDevice, s));
+  Arena& out = h->out;
+  a.nmatches = out.put((const int*)nullptr, 4), a.m12 = out.put((const int*)nullptr, n1);
+  a.n1 = n1, a.nqe = nqe, a.onlyStereo = only_stereo, a.coarse = coarse, a.th = th_low, a.check_ori = check_ori, a.binOf = h->binOf.p;
+  if (n1) HIP_TRYM(hipMemsetAsync(a.m12, 0xff, (size_t)n1 * 4, s));
+  if (nqe > 0) hipLaunchKernelGGL(k_tri_search, dim3((nqe + 3) / 4), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_tri_finish, dim3(1), dim3(256), 0, s, a);
+  HIP_TRYM(hipGetLastError());
+  HIP_TRYM(hipMemcpyAsync(out.h, out.d, out.off, hipMemcpyDeviceToHost, s));
+  HIP_TRYM(hipStreamSynchronize(s));
+  if (n1) memcpy(matches12, out.host_of(a.m12), (size_t)n1 * 4);
+  return *out.host_of(a.nmatches);
 }
 
 // Frame::AssignFeaturesToGrid for the frames of an extraction batch, device-resident (see k_assign_grid).

@@ -119,7 +119,7 @@ class ORBmatcher:
         return n, m12, pm
 
     def SearchByProjection(self, last_desc, last_uv, last_octave, last_angle, cur_kps, cur_desc, scale_factors, th, bounds, last_valid=None,
-                           last_invz=None, cur_u_right=None, cur_occupied=None, direction=0, mbf=0.0, check_ori=None):
+                           last_invz=None, cur_u_right=None, cur_occupied=None, direction=0, mbf=0.0, check_ori=None, th_dist=None):
         """SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, th, bMono) (src/ORBmatcher.cc:1684-1908, Nleft == -1) on
         arrays: last_* describe the last frame's MapPoints already projected into the current frame by the caller, cur_kps are the
         current frame's undistorted keypoints (KP_DTYPE), bounds = (mnMinX, mnMaxX, mnMinY, mnMaxY), direction 0 / 1 (bForward) /
@@ -138,7 +138,7 @@ class ORBmatcher:
         n = check(
             _lib.lib().orbm_search_by_projection(
                 self._h, ptr(d1), ptr(uv), ptr(iz), ptr(oc), ptr(an), ptr(lv), n1, ptr(d2), ptr(kp2), ptr(ur), ptr(occ), n2, ptr(sf), len(sf), float(th),
-                int(direction), float(mbf), float(bounds[0]), float(bounds[1]), float(bounds[2]), float(bounds[3]), self.TH_HIGH,
+                int(direction), float(mbf), float(bounds[0]), float(bounds[1]), float(bounds[2]), float(bounds[3]), self.TH_HIGH if th_dist is None else int(th_dist),
                 int(self.mbCheckOrientation if check_ori is None else check_ori), ptr(col), ptr(loc),
             ),
             "orbm_search_by_projection",
@@ -168,6 +168,86 @@ class ORBmatcher:
             "orbm_search_by_projection_map",
         )
         return n, com, moc
+
+    def SearchByProjectionKeyFrame(self, kf_mp_desc, mp_uv, mp_level, kf_angle, cur_kps, cur_desc, scale_factors, th, ORBdist, bounds, mp_valid=None,
+                                   cur_occupied=None):
+        """SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, sAlreadyFound, th, ORBdist) (src/ORBmatcher.cc:1910-2036), the relocalisation
+        search: mp_level = PredictScale(dist3D, &CurrentFrame), kf_angle = pKF->mvKeysUn[i].angle, mp_valid = MapPoint present, not bad, not
+        in sAlreadyFound, inside the bounds and the distance range; cur_occupied = CurrentFrame.mvpMapPoints[i2] != NULL.  Same window, level
+        range [level - 1, level + 1], closing rule and rotation histogram as the Frame-to-Frame search, with threshold ORBdist."""
+        return self.SearchByProjection(kf_mp_desc, mp_uv, mp_level, kf_angle, cur_kps, cur_desc, scale_factors, th, bounds, last_valid=mp_valid,
+                                       cur_occupied=cur_occupied, direction=0, th_dist=int(ORBdist))
+
+    def _search_in_windows(self, q_desc, q_uv, q_level, t_kps, t_desc, scale_factors, th, bounds, th_dist, claim, q_valid=None, q_ur=None,
+                           t_u_right=None, t_occupied=None, inv_level_sigma2=None):
+        d1 = np.ascontiguousarray(q_desc, np.uint8).reshape(-1, 32)
+        d2 = np.ascontiguousarray(t_desc, np.uint8).reshape(-1, 32)
+        kp2 = np.ascontiguousarray(t_kps, KP_DTYPE)
+        n1, n2 = len(d1), len(d2)
+        uv = np.ascontiguousarray(q_uv, np.float32).reshape(-1, 2)
+        lv = np.ascontiguousarray(q_level, np.int32)
+        sf = np.ascontiguousarray(scale_factors, np.float32)
+        opt = lambda a, dt: None if a is None else np.ascontiguousarray(a, dt)
+        va, qr, ur, occ, s2 = opt(q_valid, np.uint8), opt(q_ur, np.float32), opt(t_u_right, np.float32), opt(t_occupied, np.uint8), opt(inv_level_sigma2, np.float32)
+        toq = np.zeros(n1, np.int32)
+        n = check(
+            _lib.lib().orbm_search_in_windows(
+                self._h, ptr(d1), ptr(uv), ptr(qr), ptr(lv), ptr(va), n1, ptr(d2), ptr(kp2), ptr(ur), ptr(occ), n2, ptr(sf), ptr(s2), len(sf), float(th),
+                int(claim), float(bounds[0]), float(bounds[1]), float(bounds[2]), float(bounds[3]), int(th_dist), ptr(toq),
+            ),
+            "orbm_search_in_windows",
+        )
+        return n, toq
+
+    def SearchByProjectionSim3(self, mp_desc, mp_uv, mp_level, kf_kps, kf_desc, scale_factors, th, ratioHamming, bounds, mp_valid=None, kf_matched=None):
+        """SearchByProjection(KeyFrame* pKF, Sim3f& Scw, vpPoints, vpMatched, th, ratioHamming) (src/ORBmatcher.cc:423-538; :540-664 is the same
+        search): kf_matched[idx] = (vpMatched[idx] != NULL) before the call.  Returns (nmatches, kf_of_point[n1])."""
+        th_dist = int(np.floor(np.float32(self.TH_LOW) * np.float32(ratioHamming)))  # bestDist <= TH_LOW * ratioHamming (:516)
+        return self._search_in_windows(mp_desc, mp_uv, mp_level, kf_kps, kf_desc, scale_factors, th, bounds, th_dist, 1, q_valid=mp_valid, t_occupied=kf_matched)
+
+    def Fuse(self, mp_desc, mp_uv, mp_level, kf_kps, kf_desc, scale_factors, th, bounds, mp_valid=None, inv_level_sigma2=None, mp_ur=None, kf_u_right=None):
+        """The search of Fuse(KeyFrame*, vpMapPoints, th, bRight) (src/ORBmatcher.cc:1149-1328; pass inv_level_sigma2 = mvInvLevelSigma2, and for
+        stereo keyframes mp_ur / kf_u_right) and of Fuse(KeyFrame*, Sim3f&, vpPoints, th, vpReplacePoint) (:1330-1452; no gate).  Returns
+        (nFused, kf_of_point[n1]); Replace / AddObservation on the result stay with the caller."""
+        return self._search_in_windows(mp_desc, mp_uv, mp_level, kf_kps, kf_desc, scale_factors, th, bounds, self.TH_LOW, 0, q_valid=mp_valid, q_ur=mp_ur,
+                                       t_u_right=kf_u_right, inv_level_sigma2=inv_level_sigma2)
+
+    def SearchBySim3(self, mp1_desc, uv1in2, level1in2, valid1, kps1, desc1, mp2_desc, uv2in1, level2in1, valid2, kps2, desc2, scale_factors, th, bounds):
+        """SearchBySim3(pKF1, pKF2, vpMatches12, S12, th) (src/ORBmatcher.cc:1454-1682): KF1's MapPoints searched in KF2 and KF2's in KF1 (each
+        point on its own, TH_HIGH), kept where the two directions agree (:1661-1673).  Returns (nFound, idx2_of_idx1[N1])."""
+        _, m1 = self._search_in_windows(mp1_desc, uv1in2, level1in2, kps2, desc2, scale_factors, th, bounds, self.TH_HIGH, 0, q_valid=valid1)
+        _, m2 = self._search_in_windows(mp2_desc, uv2in1, level2in1, kps1, desc1, scale_factors, th, bounds, self.TH_HIGH, 0, q_valid=valid2)
+        out = np.full(len(m1), -1, np.int32)
+        ok = m1 >= 0
+        ok[ok] = m2[m1[ok]] == np.nonzero(ok)[0]
+        out[ok] = m1[ok]
+        return int(ok.sum()), out
+
+    def SearchForTriangulation(self, kps1, desc1, has_mp1, featvec1, kps2, desc2, has_mp2, featvec2, F12, ep, scale_factors, level_sigma2,
+                               stereo1=None, stereo2=None, bOnlyStereo=False, bCoarse=False):
+        """SearchForTriangulation(pKF1, pKF2, vMatchedPairs, bOnlyStereo, bCoarse) (src/ORBmatcher.cc:916-1147) for keyframes of one pinhole
+        camera: featvec = {node: [features]} (or pre-flattened groups passed as featvec1 with featvec2 = None); F12 = K1^-T [t12]x R12 K2^-1
+        (3 x 3), ep = KF1's centre projected into KF2.  Returns (nmatches, vMatchedPairs as an (n, 2) array)."""
+        groups = featvec1 if featvec2 is None else flatten_feature_vectors(featvec1, featvec2)
+        qo, qi, to, ti = (np.ascontiguousarray(g, np.int32) for g in groups)
+        kp1, kp2 = np.ascontiguousarray(kps1, KP_DTYPE), np.ascontiguousarray(kps2, KP_DTYPE)
+        d1 = np.ascontiguousarray(desc1, np.uint8).reshape(-1, 32)
+        d2 = np.ascontiguousarray(desc2, np.uint8).reshape(-1, 32)
+        opt = lambda x: None if x is None else np.ascontiguousarray(x, np.uint8)
+        m1, m2, s1, s2 = opt(has_mp1), opt(has_mp2), opt(stereo1), opt(stereo2)
+        F = np.ascontiguousarray(F12, np.float32).reshape(9)
+        e = np.ascontiguousarray(ep, np.float32).reshape(2)
+        sf, sg = np.ascontiguousarray(scale_factors, np.float32), np.ascontiguousarray(level_sigma2, np.float32)
+        m12 = np.zeros(len(kp1), np.int32)
+        n = check(
+            _lib.lib().orbm_search_for_triangulation(
+                self._h, ptr(d1), ptr(kp1), ptr(m1), ptr(s1), len(kp1), ptr(d2), ptr(kp2), ptr(m2), ptr(s2), len(kp2), len(qo) - 1, ptr(qo), ptr(qi), ptr(to),
+                ptr(ti), ptr(F), ptr(e), ptr(sf), ptr(sg), len(sf), int(bOnlyStereo), int(bCoarse), self.TH_LOW, int(self.mbCheckOrientation), ptr(m12),
+            ),
+            "orbm_search_for_triangulation",
+        )
+        i1 = np.nonzero(m12 >= 0)[0]
+        return n, np.stack([i1, m12[i1]], 1).astype(np.int64)
 
     def match_bruteforce_device(self, d_q, d_q_kp, d_nq, cap_q, d_t, d_t_kp, d_nt, cap_t, d_match, d_nmatches, th=None, strict_lt=False, stream=None):
         """Device-resident brute-force SearchByBoW (one group): enqueue only."""

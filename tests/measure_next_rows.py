@@ -30,7 +30,7 @@ def timeit(fn, reps):
 
 
 def main():
-    for fn in (row_n1, row_n2, row_n3, row_n3_map, row_n3_batch):
+    for fn in (row_n1, row_n2, row_n3, row_n3_map, row_a13_windows, row_a13_triangulation, row_n3_batch):
         print(json.dumps(fn()), flush=True)
 
 
@@ -145,6 +145,70 @@ def row_n3_map():
     tc = timeit(lambda: O.search_by_projection_map(dA, uv, None, level, radius, None, dB, kB, None, None, sf, 0.8, bounds, 100), 20)
     return {"row": "N3 SearchByProjection(Frame, MapPoints)", "workload": "%d MapPoints vs %d features, th = 3, %d matches" % (len(kA), len(kB), ref[0]),
             "gpu_ms_per_call": tg * 1e3, "cpu_oracle_ms_per_call": tc * 1e3, "speedup": tc / tg, "includes": "host grid build, H2D, 2 kernels, D2H"}
+
+
+def row_a13_windows():
+    """SearchByProjection(KeyFrame, Sim3) (closing search) and Fuse (gate, every point on its own) through orbm_search_in_windows."""
+    frames = synth.make_stream(480, 640, 2, camera_idx=5)
+    oex = O.OracleExtractor(1000, 1.2, 8, 20, 7)
+    _, kA, dA = oex(frames[0], (0, 1000))
+    _, kB, dB = oex(frames[1], (0, 1000))
+    sf = oex.scale_tables()[0]
+    s2 = (np.float32(1.0) / (sf * sf)).astype(np.float32)
+    rng = np.random.default_rng(43)
+    _, mq, _ = O.match_groups(dA, dB, kA["angle"], kB["angle"], 50, 0.7, False, True)
+    ok = mq >= 0
+    shift = np.median(np.stack([kB["x"][mq[ok]] - kA["x"][ok], kB["y"][mq[ok]] - kA["y"][ok]], 1), axis=0)
+    uv = (np.stack([kA["x"], kA["y"]], 1) + shift + rng.normal(0, 1.0, (len(kA), 2))).astype(np.float32)
+    level = np.clip(kA["octave"] + rng.integers(0, 2, len(kA)), 0, 7).astype(np.int32)
+    bounds = (0.0, 640.0, 0.0, 480.0)
+    m = ORBmatcher(0.8, True)
+    ref = O.search_in_windows(dA, uv, None, level, None, dB, kB, None, None, sf, None, 4.0, 1, bounds, 50)
+    got = m.SearchByProjectionSim3(dA, uv, level, kB, dB, sf, 4.0, 1.0, bounds)
+    assert ref[0] == got[0] and ref[1].tolist() == got[1].tolist()
+    reff = O.search_in_windows(dA, uv, None, level, None, dB, kB, None, None, sf, s2, 3.0, 0, bounds, 50)
+    gotf = m.Fuse(dA, uv, level, kB, dB, sf, 3.0, bounds, inv_level_sigma2=s2)
+    assert reff[0] == gotf[0] and reff[1].tolist() == gotf[1].tolist()
+    tg = timeit(lambda: m.SearchByProjectionSim3(dA, uv, level, kB, dB, sf, 4.0, 1.0, bounds), 50)
+    tc = timeit(lambda: O.search_in_windows(dA, uv, None, level, None, dB, kB, None, None, sf, None, 4.0, 1, bounds, 50), 20)
+    tgf = timeit(lambda: m.Fuse(dA, uv, level, kB, dB, sf, 3.0, bounds, inv_level_sigma2=s2), 50)
+    tcf = timeit(lambda: O.search_in_windows(dA, uv, None, level, None, dB, kB, None, None, sf, s2, 3.0, 0, bounds, 50), 20)
+    return {"row": "A13 SearchByProjection(KeyFrame, Sim3) / Fuse", "workload": "%d points vs %d features, th = 4 / 3, %d / %d matches" % (len(kA), len(kB), ref[0], reff[0]),
+            "gpu_ms_per_call": tg * 1e3, "cpu_oracle_ms_per_call": tc * 1e3, "speedup": tc / tg, "fuse_gpu_ms_per_call": tgf * 1e3,
+            "fuse_cpu_oracle_ms_per_call": tcf * 1e3, "includes": "host grid build, H2D, 2 kernels, D2H"}
+
+
+def row_a13_triangulation():
+    frames = synth.make_stream(480, 640, 2, camera_idx=2)
+    oex = O.OracleExtractor(1000, 1.2, 8, 20, 7)
+    _, kA, dA = oex(frames[0], (0, 1000))
+    _, kB, dB = oex(frames[1], (0, 1000))
+    sf = oex.scale_tables()[0]
+    sg = (sf * sf).astype(np.float32)
+    q_off, q_idx, t_off, t_idx = [0], [], [0], []
+    for node in range(64):  # stand-in for the level-4 nodes of a vocabulary: split on six descriptor bits
+        f1, f2 = np.nonzero(dA[:, 0] >> 2 == node)[0], np.nonzero(dB[:, 0] >> 2 == node)[0]
+        if len(f1) and len(f2):
+            q_idx += f1.tolist()
+            t_idx += f2.tolist()
+            q_off.append(len(q_idx))
+            t_off.append(len(t_idx))
+    groups = tuple(np.asarray(a, np.int32) for a in (q_off, q_idx, t_off, t_idx))
+    _, mq, _ = O.match_groups(dA, dB, kA["angle"], kB["angle"], 50, 0.7, False, True)
+    ok = mq >= 0
+    dx, dy = float(np.median(kB["x"][mq[ok]] - kA["x"][ok])), float(np.median(kB["y"][mq[ok]] - kA["y"][ok]))
+    t = np.array([dx, dy, 0.0]) / max(1e-6, np.hypot(dx, dy))
+    Ki = np.linalg.inv(np.array([[460.0, 0, 320.0], [0, 455.0, 240.0], [0, 0, 1]]))
+    F = (Ki.T @ np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]]) @ Ki).astype(np.float32)
+    ep = np.array([1e6, 240.0], np.float32)
+    m = ORBmatcher(0.6, True)
+    ref = O.search_for_triangulation(dA, kA, None, None, dB, kB, None, None, groups, F, ep, sf, sg)
+    got = m.SearchForTriangulation(kA, dA, None, groups, kB, dB, None, None, F, ep, sf, sg)
+    assert ref[0] == got[0] and got[1][:, 1].tolist() == ref[1][ref[1] >= 0].tolist()
+    tg = timeit(lambda: m.SearchForTriangulation(kA, dA, None, groups, kB, dB, None, None, F, ep, sf, sg), 50)
+    tc = timeit(lambda: O.search_for_triangulation(dA, kA, None, None, dB, kB, None, None, groups, F, ep, sf, sg), 20)
+    return {"row": "A13 SearchForTriangulation", "workload": "%d x %d features in %d common nodes, %d matches" % (len(kA), len(kB), len(q_off) - 1, ref[0]),
+            "gpu_ms_per_call": tg * 1e3, "cpu_oracle_ms_per_call": tc * 1e3, "speedup": tc / tg, "includes": "H2D, 2 kernels, D2H"}
 
 
 def row_n3_batch():

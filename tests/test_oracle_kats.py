@@ -477,3 +477,109 @@ def test_search_by_projection_map_kat(oracle):
     # predicted level 2: only levels 1..2 qualify (feature 2 on level 0 is out); predicted level 0: levels -1..0 -> only feature 2
     n, com, _ = oracle.search_by_projection_map(q, uv, None, np.array([0], np.int32), np.array([4.0], np.float32), None, dcur, cur, None, None, sf, 0.9, bounds, 100)
     assert n == 1 and com.tolist() == [2]
+
+
+def test_search_in_windows_kat(oracle):
+    """The windowed search of SearchByProjection(KeyFrame, Sim3) / Fuse / SearchBySim3 (src/ORBmatcher.cc:423-538, 1149-1452, 1499-1658):
+    levels [predicted - 1, predicted], first minimum, closing of matched features, Fuse's chi-square gate (5.99 mono / 7.8 stereo)."""
+    KP = oracle.KP_DTYPE
+    kf = np.zeros(4, KP)
+    kf["x"], kf["y"], kf["octave"] = [100, 102, 104, 100], [100, 100, 100, 103], [1, 1, 0, 2]
+    dkf = np.zeros((4, 32), np.uint8)
+    dkf[0, 0], dkf[1, 0], dkf[2, 0], dkf[3, 0] = 0x0F, 0x0F, 0x01, 0x00  # 4, 4, 1, 0 bits from the zero query
+    sf = np.array([1.0, 1.2, 1.44], np.float32)
+    s2 = (1.0 / (sf * sf)).astype(np.float32)
+    bounds = (0.0, 640.0, 0.0, 480.0)
+    q2 = np.zeros((2, 32), np.uint8)
+    uv2 = np.array([[101, 100], [101, 100]], np.float32)
+    lv1 = np.array([1, 1], np.int32)
+    # level 1 -> levels 0..1: feature 3 (level 2, distance 0) is out; feature 2 (1 bit) wins for both points when they do not interact
+    n, t = oracle.search_in_windows(q2, uv2, None, lv1, None, dkf, kf, None, None, sf, None, 5.0, 0, bounds, 50)
+    assert n == 2 and t.tolist() == [2, 2]
+    # closing search: the second point finds feature 2 taken and falls to the FIRST of the tied features 0 / 1 in scan order
+    n, t = oracle.search_in_windows(q2, uv2, None, lv1, None, dkf, kf, None, None, sf, None, 5.0, 1, bounds, 50)
+    assert n == 2 and t.tolist() == [2, 0]
+    # occupied features are skipped from the start; threshold 3 then rejects the 4-bit candidates
+    occ = np.array([0, 0, 1, 0], np.uint8)
+    n, t = oracle.search_in_windows(q2, uv2, None, lv1, None, dkf, kf, None, occ, sf, None, 5.0, 1, bounds, 3)
+    assert n == 0 and t.tolist() == [-1, -1]
+    # level 2 -> levels 1..2: feature 3 (distance 0) wins; radius 2.0 * 1.44 = 2.88 < 3 px away in y -> window excludes it again
+    n, t = oracle.search_in_windows(q2[:1], uv2[:1], None, np.array([2], np.int32), None, dkf, kf, None, None, sf, None, 5.0, 0, bounds, 50)
+    assert n == 1 and t.tolist() == [3]
+    n, t = oracle.search_in_windows(q2[:1], uv2[:1], None, np.array([2], np.int32), None, dkf, kf, None, None, sf, None, 2.0, 0, bounds, 50)
+    assert n == 1 and t.tolist() == [0]
+    # Fuse gate, monocular: feature 2 is 3 px away on level 0 -> e2 * invSigma2 = 9 > 5.99 rejects it; features 0 / 1 are 1 px away on
+    # level 1 -> 1 / 1.44 passes -> first of the tie
+    n, t = oracle.search_in_windows(q2[:1], uv2[:1], None, lv1[:1], None, dkf, kf, None, None, sf, s2, 5.0, 0, bounds, 50)
+    assert n == 1 and t.tolist() == [0]
+    # stereo: feature 0 has a right coordinate 3 px from the predicted one: (1 + 9) / 1.44 = 6.94 <= 7.8 passes;
+    # 3.5 px: (1 + 12.25) / 1.44 = 9.2 > 7.8 rejects -> feature 1 (no right coordinate, mono gate) takes over
+    ur = np.array([80.0, -1.0, -1.0, -1.0], np.float32)
+    n, t = oracle.search_in_windows(q2[:1], uv2[:1], np.array([83.0], np.float32), lv1[:1], None, dkf, kf, ur, None, sf, s2, 5.0, 0, bounds, 50)
+    assert n == 1 and t.tolist() == [0]
+    n, t = oracle.search_in_windows(q2[:1], uv2[:1], np.array([83.5], np.float32), lv1[:1], None, dkf, kf, ur, None, sf, s2, 5.0, 0, bounds, 50)
+    assert n == 1 and t.tolist() == [1]
+    # invalid points and empty sides
+    n, t = oracle.search_in_windows(q2, uv2, None, lv1, np.array([0, 1], np.uint8), dkf, kf, None, None, sf, None, 5.0, 1, bounds, 50)
+    assert n == 1 and t.tolist() == [-1, 2]
+    n, t = oracle.search_in_windows(q2, uv2, None, lv1, None, np.zeros((0, 32), np.uint8), np.zeros(0, KP), None, None, sf, None, 5.0, 1, bounds, 50)
+    assert n == 0 and t.tolist() == [-1, -1]
+
+
+def _f12_pure_translation_x(fx, fy, cx, cy, tx=1.0):
+    """F12 = K^-T [t]x R K^-1 for R = I, t = (tx, 0, 0): epipolar lines are the image rows (a = 0, b = -tx/fy .., c = ..)."""
+    K = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1]], np.float64)
+    tx_ = np.array([[0, 0, 0], [0, 0, -tx], [0, tx, 0]], np.float64)
+    Ki = np.linalg.inv(K)
+    return (Ki.T @ tx_ @ Ki).astype(np.float32)
+
+
+def test_search_for_triangulation_kat(oracle):
+    """SearchForTriangulation (src/ORBmatcher.cc:916-1147): same-node candidates only, MapPoint holders skipped, epipole and epipolar
+    gates, `dist > bestDist -> continue` (the last of equals wins), no closing of matched features, rotation histogram."""
+    KP = oracle.KP_DTYPE
+    F = _f12_pure_translation_x(500.0, 500.0, 320.0, 240.0)
+    sf = (np.float32(1.2) ** np.arange(8)).astype(np.float32)
+    sg = (sf * sf).astype(np.float32)
+    ep = np.array([5000.0, 240.0], np.float32)  # far outside the image
+    k1 = np.zeros(3, KP)
+    k1["x"], k1["y"] = [100, 200, 300], [100, 200, 300]
+    k2 = np.zeros(5, KP)
+    k2["x"], k2["y"] = [110, 120, 130, 210, 310], [100, 100.5, 104, 200, 300]
+    d1 = np.zeros((3, 32), np.uint8)
+    d2 = np.zeros((5, 32), np.uint8)
+    d2[0, 0], d2[1, 0], d2[2, 0] = 0x03, 0x03, 0x00  # 2, 2, 0 bits; feature 2 is 4 px off the epipolar row
+    groups = (np.array([0, 1, 2], np.int32), np.array([0, 1], np.int32), np.array([0, 3, 4], np.int32), np.array([0, 1, 2, 3], np.int32))
+    args = dict(F12=F, ep=ep, scale_factors=sf, level_sigma2=sg)
+    # feature 0: candidates 0, 1 (on the row: |dy| <= 0.5 -> d^2 <= 0.25 < 3.84), 2 (16 > 3.84 rejected although closest in Hamming);
+    # ties 0 / 1 -> the LAST one; feature 1 -> 3; feature 2 is in no common node; KF2 feature 4 is in no group
+    n, m = oracle.search_for_triangulation(d1, k1, None, None, d2, k2, None, None, groups, check_ori=False, **args)
+    assert n == 2 and m.tolist() == [1, 3, -1]
+    # coarse: no epipolar test -> the 0-bit candidate wins
+    n, m = oracle.search_for_triangulation(d1, k1, None, None, d2, k2, None, None, groups, check_ori=False, coarse=True, **args)
+    assert n == 2 and m.tolist() == [2, 3, -1]
+    # MapPoint holders on either side are skipped
+    n, m = oracle.search_for_triangulation(d1, k1, np.array([0, 1, 0], np.uint8), None, d2, k2, np.array([0, 1, 0, 0, 0], np.uint8), None, groups, check_ori=False, **args)
+    assert n == 1 and m.tolist() == [0, -1, -1]
+    # epipole 5 px from candidate 1 (25 < 100 * 1.0) -> dropped for monocular pairs, kept when either side is stereo
+    ep2 = np.array([125.0, 100.5], np.float32)
+    n, m = oracle.search_for_triangulation(d1, k1, None, None, d2, k2, None, None, groups, F, ep2, sf, sg, check_ori=False)
+    assert m.tolist() == [0, 3, -1]  # candidate 0 is 15 px away: 225 > 100 -> kept
+    n, m = oracle.search_for_triangulation(d1, k1, None, None, d2, k2, None, np.array([0, 1, 0, 0, 0], np.uint8), groups, F, ep2, sf, sg, check_ori=False)
+    assert m.tolist() == [1, 3, -1]
+    # bOnlyStereo needs both sides stereo
+    st1, st2 = np.array([1, 0, 0], np.uint8), np.array([1, 0, 0, 1, 0], np.uint8)
+    n, m = oracle.search_for_triangulation(d1, k1, None, st1, d2, k2, None, st2, groups, only_stereo=True, check_ori=False, **args)
+    assert n == 1 and m.tolist() == [0, -1, -1]
+    # two KF1 features may take the same KF2 feature (vbMatched2 is never set)
+    g2 = (np.array([0, 2], np.int32), np.array([0, 1], np.int32), np.array([0, 1], np.int32), np.array([3], np.int32))
+    k1b = k1.copy()
+    k1b["y"][0] = 200
+    n, m = oracle.search_for_triangulation(d1, k1b, None, None, d2, k2, None, None, g2, check_ori=False, **args)
+    assert n == 2 and m.tolist() == [3, 3, -1]
+    # threshold: 51 differing bits are out, 50 are in
+    d2c = d2.copy()
+    d2c[3, :7] = [0xFF] * 6 + [0x07]
+    assert oracle.search_for_triangulation(d1, k1, None, None, d2c, k2, None, None, groups, check_ori=False, **args)[1].tolist() == [1, -1, -1]
+    d2c[3, 6] = 0x03
+    assert oracle.search_for_triangulation(d1, k1, None, None, d2c, k2, None, None, groups, check_ori=False, **args)[1].tolist() == [1, 3, -1]
