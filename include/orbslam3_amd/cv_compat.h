@@ -24,6 +24,8 @@ namespace orbx_cv {
 typedef unsigned char uchar;
 struct Point2f {
   float x = 0, y = 0;
+  Point2f() {}
+  Point2f(float x_, float y_) : x(x_), y(y_) {}
 };
 struct KeyPoint {  // layout of cv::KeyPoint
   Point2f pt;

@@ -1759,6 +1759,12 @@ int orbm_search_in_windows(orbm_t* h, const uint8_t* q_desc, const float* q_uv, 
     set_err("orbm_search_in_windows: bad arguments");
     return -2;
   }
+  if (inv_level_sigma2 && t_kp)  // the gate indexes mvInvLevelSigma2 by the keypoint's level
+    for (int i = 0; i < n2; i++)
+      if (t_kp[i].octave < 0 || t_kp[i].octave >= nlevels) {
+        set_err("orbm_search_in_windows: keypoint octave outside the scale table");
+        return -2;
+      }
   if (claim)  // mode 0 with the [level - 1, level] window: occupied features are skipped, a match closes its feature
     return proj_single(h, 0, nullptr, nullptr, 0.f, q_desc, q_uv, nullptr, q_level, nullptr, q_valid, n1, t_desc, t_kp, nullptr, t_occupied, n2,
                        scale_factors, nlevels, th, 3, 0.f, min_x, max_x, min_y, max_y, th_dist, 0, t_of_q, nullptr);

@@ -68,6 +68,43 @@ int main(int argc, char** argv) {
       fprintf(o, "\n");
     }
     for (size_t j = 0; j < match2.size(); j++) fprintf(o, "%d\n", match2[j]);
+    // the projection family on arrays: frame A's keypoints "projected" into frame B by a fixed shift
+    const int                     n1 = (int)kA.size();
+    std::vector<orbx_cv::Point2f> uv(n1);
+    std::vector<int>              lvl(n1);
+    std::vector<float>            invz, radius(n1, 4.0f * 3.0f), s2(sf.size()), sg(sf.size());
+    std::vector<unsigned char>    valid;
+    for (int i = 0; i < n1; i++) uv[i] = orbx_cv::Point2f(kA[i].pt.x + 3.0f, kA[i].pt.y + 1.0f), lvl[i] = kA[i].octave;
+    for (size_t l = 0; l < sf.size(); l++) sg[l] = sf[l] * sf[l], s2[l] = 1.0f / sg[l];
+    const float      bounds[4] = {0.f, (float)cols, 0.f, (float)rows};
+    std::vector<int> r;
+    auto             dump = [&](int n) {
+      fprintf(o, "%d", n);
+      for (int v : r) fprintf(o, " %d", v);
+      fprintf(o, "\n");
+    };
+    dump(matcher.SearchByProjectionArrays(dA, uv, invz, kA, valid, dB, kB, nullptr, nullptr, sf, 15.0f, 0, 0.f, bounds, r));
+    dump(matcher.SearchByProjectionMapPointsArrays(dA, uv, invz, lvl, radius, valid, dB, kB, nullptr, nullptr, sf, bounds, r));
+    dump(matcher.SearchByProjectionKeyFrameArrays(dA, uv, lvl, aA, valid, dB, kB, nullptr, sf, 10.0f, 64, bounds, r));
+    dump(matcher.SearchInWindowsArrays(dA, uv, nullptr, lvl, valid, dB, kB, nullptr, nullptr, sf, nullptr, 4.0f, true, 50, bounds, r));
+    dump(matcher.SearchInWindowsArrays(dA, uv, nullptr, lvl, valid, dB, kB, nullptr, nullptr, sf, &s2, 3.0f, false, 50, bounds, r));
+    std::vector<int> qOff(1, 0), qIdx, tOff(1, 0), tIdx;  // common nodes of the two FeatureVectors (merge walk of SearchByBoW)
+    for (auto& kv : gA) {
+      auto it = gB.find(kv.first);
+      if (it == gB.end()) continue;
+      for (unsigned f : kv.second) qIdx.push_back((int)f);
+      for (unsigned f : it->second) tIdx.push_back((int)f);
+      qOff.push_back((int)qIdx.size()), tOff.push_back((int)tIdx.size());
+    }
+    // F12 for a pure translation along x with fx = fy = 460, cx = 320, cy = 240: K^-T [t]x K^-1
+    const float F12[9] = {0.f, 0.f, 0.f, 0.f, 0.f, -1.0f / 460.0f, 0.f, 1.0f / 460.0f, 0.f};
+    const float ep[2]  = {1e6f, 240.f};
+    std::vector<std::pair<std::size_t, std::size_t> > pairs;
+    std::vector<unsigned char>                        none;
+    const int nt = matcher.SearchForTriangulationArrays(dA, kA, none, nullptr, dB, kB, none, nullptr, qOff, qIdx, tOff, tIdx, F12, ep, sf, sg, false, false, pairs);
+    fprintf(o, "%d", nt);
+    for (auto& pr : pairs) fprintf(o, " %zu %zu", pr.first, pr.second);
+    fprintf(o, "\n");
   }
   fclose(o);
   delete ext;

@@ -73,3 +73,29 @@ def test_adaptor_matches_oracle(tmp_path, oracle):
         assert v[0] == int(niA[i]) and v[1:] == fvA[int(niA[i])]
     b3 = base + 1 + len(wiA) + len(niA)
     assert [int(x) for x in lines[b3 : b3 + len(kB)]] == mt2.tolist()
+    # the projection family through the C++ adaptors (same inputs rebuilt here)
+    b4 = b3 + len(kB)
+    sf = oex.scale_tables()[0]
+    sg = (sf * sf).astype(np.float32)
+    s2 = (np.float32(1.0) / sg).astype(np.float32)
+    uv = np.stack([kA["x"] + np.float32(3.0), kA["y"] + np.float32(1.0)], 1).astype(np.float32)
+    lvl = kA["octave"].astype(np.int32)
+    bounds = (0.0, 640.0, 0.0, 480.0)
+    row = lambda k: [int(x) for x in lines[b4 + k].split()]
+    n, col, _ = oracle.search_by_projection(dA, uv, None, lvl, kA["angle"], None, dB, kB, None, None, sf, 15.0, 0, 0.0, bounds, 100, True)
+    assert row(0) == [n] + col.tolist() and n > 100
+    n, com, _ = oracle.search_by_projection_map(dA, uv, None, lvl, np.full(len(kA), 12.0, np.float32), None, dB, kB, None, None, sf, 0.7, bounds, 100)
+    assert row(1) == [n] + com.tolist() and n > 100
+    n, col, _ = oracle.search_by_projection(dA, uv, None, lvl, kA["angle"], None, dB, kB, None, None, sf, 10.0, 0, 0.0, bounds, 64, True)
+    assert row(2) == [n] + col.tolist()
+    n, t = oracle.search_in_windows(dA, uv, None, lvl, None, dB, kB, None, None, sf, None, 4.0, 1, bounds, 50)
+    assert row(3) == [n] + t.tolist()
+    n, t = oracle.search_in_windows(dA, uv, None, lvl, None, dB, kB, None, None, sf, s2, 3.0, 0, bounds, 50)
+    assert row(4) == [n] + t.tolist()
+    F = np.array([0, 0, 0, 0, 0, -1.0 / 460.0, 0, 1.0 / 460.0, 0], np.float32)
+    n, m12 = oracle.search_for_triangulation(dA, kA, None, None, dB, kB, None, None, flatten_feature_vectors(fvA, fvB), F, [1e6, 240.0], sf, sg)
+    want = [n]
+    for i in np.nonzero(m12 >= 0)[0]:
+        want += [int(i), int(m12[i])]
+    assert row(5) == want
+
