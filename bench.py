@@ -256,9 +256,6 @@ def main():
 
         def step(self, timed=False):
             with torch.cuda.stream(self.tstream):
-                if self.pending is not None:  # the previous gather of this lane must have drained its send buffer
-                    self.pending.wait()
-                    self.pending = None
                 self.ex.extract_batch_device(d_imgs, B, rows, cols, cols, rows * cols, self.d_kps, self.d_desc, self.d_cnt, self.cap, (0, 1000), stream=self.stream)
                 if not args.no_match:
                     if voc is not None:
@@ -285,7 +282,11 @@ def main():
                         e1.record()
                         self.match_ev.append((e0, e1))
                 if self.gather is not None:
-                    # asynchronous RCCL gather on the collective's own stream: overlaps the next chunk's extraction
+                    # Asynchronous RCCL gather on the collective's own stream.  It reads the packed copy of the records, not the
+                    # extractor's buffers, so the NEXT chunk's extraction and matching run beside it; only the next pack has to
+                    # wait for this gather to have drained the send buffer.
+                    if self.pending is not None:
+                        self.pending.wait()
                     self.pending = self.gather(self.d_kps, self.d_desc, self.d_cnt, async_op=True)
 
         def drain(self):
