@@ -188,7 +188,8 @@ int orbm_match_window(orbm_t* h, const uint8_t* d1, const orbx_keypoint_t* kp1, 
  * the camera and projecting inside the image bounds; last_uv[i] = projection, last_invz[i] = 1/z (needed only with
  * cur_u_right), last_octave / last_angle = the last frame's keypoint, last_desc = MapPoint::GetDescriptor().
  * cur_kp = undistorted keypoints; cur_u_right = mvuRight or NULL (monocular); cur_occupied[i2] = the feature already holds
- * a MapPoint with observations (NULL = none).  dir: 0 neither, 1 bForward, 2 bBackward (:1701-1702); th_dist = TH_HIGH.
+ * a MapPoint with observations (NULL = none).  dir: 0 neither, 1 bForward, 2 bBackward (:1701-1702), 3 = levels
+ * [octave - 1, octave] (the window of orbm_search_in_windows); th_dist = TH_HIGH.
  * A matched feature is closed to later points (all tracked points are taken to have observations; the zero-observation
  * temporal points of stereo/RGB-D odometry stay with the caller).  Outputs cur_of_last[n1], last_of_cur[n2] (may be NULL);
  * returns nmatches.  Host pointers, synchronous. */
