@@ -472,7 +472,6 @@ def test_search_for_triangulation(oracle):
     oex = oracle.OracleExtractor(1000, 1.2, 8, 20, 7)
     _, kA, dA = oex(frames[0], (0, 1000))
     _, kB, dB = oex(frames[1], (0, 1000))
-    groups = []
     q_off, q_idx, t_off, t_idx = [0], [], [0], []
     for node in range(16):
         f1, f2 = np.nonzero(dA[:, 0] >> 4 == node)[0], np.nonzero(dB[:, 0] >> 4 == node)[0]
