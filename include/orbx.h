@@ -57,6 +57,17 @@ int orbx_set_input_resize(orbx_t* h, int new_cols, int new_rows);
 
 int orbx_max_keypoints(orbx_t* h, int rows, int cols);
 
+/* How the two tap-rotation expressions of computeOrbDescriptor (src/ORBextractor.cc:105-106),
+ *     cvRound(pattern[idx].x * b + pattern[idx].y * a)   and   cvRound(pattern[idx].x * a - pattern[idx].y * b),
+ * are evaluated -- the one place where the reference's results depend on how it was compiled (CMakeLists.txt:10-17 builds with
+ * -O3 -march=native and g++ contracts a * b + c into an FMA by default):
+ *   1 (default)  fma(x, b, y * a) and fma(x, a, -(y * b)): what g++ 11 emits for these expressions with the reference's own flags on
+ *                any host with FMA (x86-64 Haswell or later, aarch64), i.e. the reference as its CMake builds it;
+ *   0            every product rounded, then the sum: the reference built for baseline x86-64 or with -ffp-contract=off;
+ *   2            fma(y, a, x * b) and fma(-y, b, x * a): the other legal contraction.
+ * The two forms differ in about one descriptor out of 10^5 (a tap landing on the other side of a rounding tie). */
+int orbx_set_tap_contraction(orbx_t* h, int mode);
+
 /* ORBextractor::operator()(image, mask [ignored], keypoints, descriptors, vLappingArea)
  * (src/ORBextractor.cc:1052-1138).  Host image in, host results out; synchronous.
  * kps / desc are caller-owned (cap entries, desc is cap x 32 bytes); *n_out = number of keypoints.
@@ -72,6 +83,29 @@ int orbx_extract(orbx_t* h, const uint8_t* img, int rows, int cols, size_t step_
 int orbx_extract_batch_device(orbx_t* h, const uint8_t* d_imgs, int nframes, int rows, int cols, size_t step_bytes,
                               size_t frame_stride_bytes, int lap0, int lap1, orbx_keypoint_t* d_kps, uint8_t* d_desc,
                               int* d_counts, int cap, void* stream);
+
+/* Streaming form of the same operator for HOST-resident frames (a camera rig, a stream): the call site of the reference
+ * (src/Frame.cc:202-205, 555-562) blocks per image; a host with N cameras or a recorded stream instead keeps several chunks in
+ * flight so that the upload of chunk k + 1, the kernels of chunk k and the download of chunk k - 1 overlap (three HIP streams).
+ *   orbx_extract_async  enqueues one chunk of nframes frames (frame f at imgs + f * frame_stride_bytes) and returns a ticket;
+ *                       kps [nframes][cap], desc [nframes][cap][32] and counts [nframes][2] (n, monoIndex) are HOST buffers
+ *                       that hold the results once orbx_wait(ticket) has returned.  Host memory obtained from orbx_host_alloc
+ *                       (or registered with hipHostRegister) is read / written by DMA directly; pageable memory is staged
+ *                       through pinned buffers of the handle (one extra host copy each way).  All buffers must stay valid until
+ *                       the ticket has been waited for.  At most `depth` tickets (orbx_set_async_depth, default 3, <= 8) may be
+ *                       outstanding; tickets are waited for in any order.
+ *   orbx_async_device_buffers  the device-side records of a ticket in flight and the stream its kernels were enqueued on, so
+ *                       that the caller can chain device work (orbm_match_pairs_device, orbv_transform_batch_device ...) behind
+ *                       the extraction without another upload.  Valid until the slot is reused (depth submissions later).
+ * Returns 0, -1 (empty input), -2, -3 as above. */
+void* orbx_host_alloc(size_t bytes); /* pinned host memory (hipHostMalloc); NULL on failure */
+void  orbx_host_free(void* p);
+int   orbx_set_async_depth(orbx_t* h, int depth);
+int   orbx_extract_async(orbx_t* h, const uint8_t* imgs, int nframes, int rows, int cols, size_t step_bytes, size_t frame_stride_bytes,
+                         int lap0, int lap1, orbx_keypoint_t* kps, uint8_t* desc, int* counts, int cap, int* ticket);
+int   orbx_async_device_buffers(orbx_t* h, int ticket, const orbx_keypoint_t** d_kps, const uint8_t** d_desc, const int** d_counts,
+                                void** stream);
+int   orbx_wait(orbx_t* h, int ticket);
 
 /* mvImagePyramid[level] (public member, include/ORBextractor.h:87; read by Frame::ComputeStereoMatches,
  * src/Frame.cc:950,1039-1058) of frame `frame` of the last extract call: copies the level to host memory.
@@ -126,6 +160,9 @@ typedef struct orbm_matcher orbm_t;
 
 int  orbm_create(orbm_t** out, int device_id);
 void orbm_destroy(orbm_t* h);
+/* Message of the calling thread's last failed orbm_* call.  orbx_last_error() returns the most recent message of ANY of the three
+ * families (orbx_ / orbm_ / orbv_): they share one slot per thread. */
+const char* orbm_last_error(void);
 
 /* ORBmatcher::DescriptorDistance (src/ORBmatcher.cc:2075-2089); host-side, for the call sites that
  * compare single pairs (src/Frame.cc:1019, src/MapPoint.cc:426). */

@@ -55,6 +55,8 @@ def lib():
         L.orao_ic_angle.restype = C.c_float
         L.orao_ic_angle.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int]
         L.orao_orb_descriptor.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_float, C.c_void_p]
+        L.orao_orb_descriptor_c.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_int]
+        L.orao_set_tap_contraction.argtypes = [C.c_void_p, C.c_int]
         L.orao_distribute_octtree.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int] + [C.c_int] * 5 + [C.c_void_p, C.c_int]
         L.orao_libm_sincos_deg.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.orao_sincos_port_mismatches.restype = C.c_long
@@ -89,11 +91,16 @@ def _u8img(img):
 class OracleExtractor:
     """Mirror of ORB_SLAM3::ORBextractor (include/ORBextractor.h:41-119) over the CPU oracle."""
 
-    def __init__(self, nfeatures=1000, scale_factor=1.2, nlevels=8, ini_th_fast=20, min_th_fast=7):
+    def __init__(self, nfeatures=1000, scale_factor=1.2, nlevels=8, ini_th_fast=20, min_th_fast=7, tap_contraction=1):
         self._h = lib().orao_create(nfeatures, scale_factor, nlevels, ini_th_fast, min_th_fast)
         if not self._h:
             raise ValueError("bad extractor parameters")
         self.nfeatures, self.nlevels = nfeatures, nlevels
+        self.set_tap_contraction(tap_contraction)
+
+    def set_tap_contraction(self, mode):
+        """1 = the reference as its CMake builds it on an FMA host (default), 0 = no contraction, 2 = the other fused form."""
+        lib().orao_set_tap_contraction(self._h, int(mode))
 
     def __del__(self):
         if getattr(self, "_h", None):
@@ -186,10 +193,10 @@ def ic_angle(img, x, y):
     return lib().orao_ic_angle(_p(img), img.strides[0], x, y)
 
 
-def orb_descriptor(blurred, x, y, angle_deg):
+def orb_descriptor(blurred, x, y, angle_deg, tap_contraction=1):
     img = _u8img(blurred)
     d = np.zeros(32, np.uint8)
-    lib().orao_orb_descriptor(_p(img), img.strides[0], x, y, float(angle_deg), _p(d))
+    lib().orao_orb_descriptor_c(_p(img), img.strides[0], x, y, float(angle_deg), _p(d), int(tap_contraction))
     return d
 
 

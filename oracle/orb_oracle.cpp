@@ -338,7 +338,27 @@ float icAngle(const uint8_t* img, size_t step, int px, int py, const int* u_max)
 // computeOrbDescriptor (src/ORBextractor.cc:93-139)
 const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
 
-void orbDescriptor(const uint8_t* img, size_t step, int cx, int cy, float angle_deg, uint8_t* desc) {
+// The tap coordinates `pattern[idx].x * b + pattern[idx].y * a` and `pattern[idx].x * a - pattern[idx].y * b` (:105-106) are the one
+// place of the path whose value depends on how the reference was COMPILED: its CMakeLists.txt (:10-17) builds with
+// `-O3 -march=native -std=c++20` and g++ keeps -ffp-contract=fast for C++, so on every host with FMA the two expressions are
+// contracted.  Established in this container with g++ 11.4 on that very expression (tools/h4_tap_contraction/):
+//   contraction 1 (reference as its CMake builds it on an FMA host; the default):  fma(x, b, y * a)  and  fma(x, a, -(y * b))
+//   contraction 0 (reference built for baseline x86-64, or with -ffp-contract=off): the four products rounded, then add / subtract
+//   contraction 2 (the other legal contraction, for compilers that fuse the second product): fma(y, a, x * b) and fma(-y, b, x * a)
+inline void tapRC(int contraction, float x, float y, float a, float b, int* r, int* c) {
+  if (contraction == 1) {
+    *r = cvRoundF(std::fmaf(x, b, y * a));
+    *c = cvRoundF(std::fmaf(x, a, -(y * b)));
+  } else if (contraction == 2) {
+    *r = cvRoundF(std::fmaf(y, a, x * b));
+    *c = cvRoundF(std::fmaf(-y, b, x * a));
+  } else {
+    *r = cvRoundF(x * b + y * a);
+    *c = cvRoundF(x * a - y * b);
+  }
+}
+
+void orbDescriptor(const uint8_t* img, size_t step, int cx, int cy, float angle_deg, uint8_t* desc, int contraction) {
   float          angle  = angle_deg * factorPI;
   float          a = (float)std::cos(angle), b = (float)std::sin(angle);  // libm cosf / sinf
   const uint8_t* center = img + (size_t)cy * step + cx;
@@ -348,8 +368,11 @@ void orbDescriptor(const uint8_t* img, size_t step, int cx, int cy, float angle_
     int val = 0;
     for (int k = 0; k < 8; k++) {
       int x0 = pat[4 * k + 0], y0 = pat[4 * k + 1], x1 = pat[4 * k + 2], y1 = pat[4 * k + 3];
-      int t0 = center[cvRoundF(x0 * b + y0 * a) * istep + cvRoundF(x0 * a - y0 * b)];
-      int t1 = center[cvRoundF(x1 * b + y1 * a) * istep + cvRoundF(x1 * a - y1 * b)];
+      int r0, c0, r1, c1;
+      tapRC(contraction, (float)x0, (float)y0, a, b, &r0, &c0);
+      tapRC(contraction, (float)x1, (float)y1, a, b, &r1, &c1);
+      int t0 = center[r0 * istep + c0];
+      int t1 = center[r1 * istep + c1];
       val |= (t0 < t1) << k;
     }
     desc[i] = (uint8_t)val;
@@ -535,6 +558,7 @@ struct orao_extractor {
   std::vector<Img>   pyramid, blurred;
   std::vector<std::vector<KP>> candidates;  // per level, feed order (debug access)
   std::vector<std::vector<KP>> levelKps;    // per level after octree + orientation
+  int                tapContraction = 1;    // see orbDescriptor
 
   // src/ORBextractor.cc:403-465
   orao_extractor(int nf, float sf, int nl, int ini, int mn) : nfeatures(nf), nlevels(nl), iniThFAST(ini), minThFAST(mn), scaleFactor(sf) {
@@ -682,7 +706,7 @@ struct orao_extractor {
       gaussianBlur7(im.d.data(), im.w, im.h, im.w, blurred[level].d.data(), im.w);
       float scale = mvScaleFactor[level];
       for (KP& kp : keypoints) {
-        orbDescriptor(blurred[level].d.data(), im.w, cvRoundF(kp.x), cvRoundF(kp.y), kp.angle, d);
+        orbDescriptor(blurred[level].d.data(), im.w, cvRoundF(kp.x), cvRoundF(kp.y), kp.angle, d, tapContraction);
         KP o = kp;
         if (level != 0) {
           o.x *= scale;
@@ -784,8 +808,16 @@ float orao_ic_angle(const uint8_t* img, size_t step, int x, int y) {
   static const int um[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
   return icAngle(img, step, x, y, um);
 }
+void orao_set_tap_contraction(orao_extractor_t* h, int mode) {
+  if (h && mode >= 0 && mode <= 2) h->tapContraction = mode;
+}
+
+void orao_orb_descriptor_c(const uint8_t* blurred, size_t step, int x, int y, float angle_deg, uint8_t* desc32, int contraction) {
+  orbDescriptor(blurred, step, x, y, angle_deg, desc32, contraction);
+}
+
 void orao_orb_descriptor(const uint8_t* blurred, size_t step, int x, int y, float angle_deg, uint8_t* desc32) {
-  orbDescriptor(blurred, step, x, y, angle_deg, desc32);
+  orbDescriptor(blurred, step, x, y, angle_deg, desc32, 1);
 }
 int orao_distribute_octtree(const float* xs, const float* ys, const float* resp, int n, int min_x, int max_x, int min_y,
                             int max_y, int n_target, int* out_idx, int cap) {

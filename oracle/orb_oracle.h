@@ -66,6 +66,10 @@ float orao_fast_atan2(float y, float x);
 int   orao_cv_round_f(float v);
 float orao_ic_angle(const uint8_t* img, size_t step, int x, int y);
 void  orao_orb_descriptor(const uint8_t* blurred, size_t step, int x, int y, float angle_deg, uint8_t* desc32);
+/* Tap-rotation contraction (src/ORBextractor.cc:105-106 as compiled): 1 = g++ -O3 -march=native on an FMA host (the reference's own
+ * CMake flags; default), 0 = no contraction, 2 = the other fused form.  See orbDescriptor in orb_oracle.cpp. */
+void  orao_orb_descriptor_c(const uint8_t* blurred, size_t step, int x, int y, float angle_deg, uint8_t* desc32, int contraction);
+void  orao_set_tap_contraction(orao_extractor_t*, int mode);
 /* DistributeOctTree (src/ORBextractor.cc:556-753): returns the number of kept points, their indices
  * into the input arrays in output (list) order.  -2 if nIni == 0. */
 int orao_distribute_octtree(const float* xs, const float* ys, const float* resp, int n, int min_x, int max_x,

@@ -31,8 +31,15 @@ SIGNATURES = {
     "orbx_get_features_per_level": (None, [_vp, _vp]),
     "orbx_set_input_resize": (_i, [_vp, _i, _i]),
     "orbx_max_keypoints": (_i, [_vp, _i, _i]),
+    "orbx_set_tap_contraction": (_i, [_vp, _i]),
     "orbx_extract": (_i, [_vp, _vp, _i, _i, _sz, _i, _i, _vp, _vp, _i, _ip]),
     "orbx_extract_batch_device": (_i, [_vp, _vp, _i, _i, _i, _sz, _sz, _i, _i, _vp, _vp, _vp, _i, _vp]),
+    "orbx_host_alloc": (_vp, [_sz]),
+    "orbx_host_free": (None, [_vp]),
+    "orbx_set_async_depth": (_i, [_vp, _i]),
+    "orbx_extract_async": (_i, [_vp, _vp, _i, _i, _i, _sz, _sz, _i, _i, _vp, _vp, _vp, _i, _ip]),
+    "orbx_async_device_buffers": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
+    "orbx_wait": (_i, [_vp, _i]),
     "orbx_undistort_keypoints": (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp]),
     "orbx_undistort_keypoints_device": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _vp]),
     "orbx_image_bounds": (_i, [_i, _i, _vp, _vp, _i, _vp]),
@@ -49,6 +56,7 @@ SIGNATURES = {
     "orbx_debug_octree_device": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _ip]),
     "orbm_create": (_i, [C.POINTER(_vp), _i]),
     "orbm_destroy": (None, [_vp]),
+    "orbm_last_error": (C.c_char_p, []),
     "orbm_hamming": (_i, [_vp, _vp]),
     "orbm_three_maxima": (None, [_vp, _i, _ip, _ip, _ip]),
     "orbm_match_groups": (_i, [_vp, _vp, _i, _vp, _i, _i] + [_vp] * 8 + [_i, _i, _f, _i, _vp, _vp]),

@@ -107,6 +107,31 @@ struct orbx_extractor {
   size_t             hInCap = 0;
   bool               overlapBlur = false;
   bool               profiling = false;
+  int                tapMode = 1;  // orbx_set_tap_contraction
+  // ---- streaming entry points (orbx_extract_async / orbx_wait): a ring of in-flight chunks.  Chunk k's upload runs on the
+  // copy-in stream, its kernels on the handle's stream, its download on the copy-out stream, so three consecutive chunks
+  // overlap: H2D(k + 1) || kernels(k) || D2H(k - 1).  The extractor's own workspace (pyramid, candidates, ...) is shared: kernels of
+  // consecutive chunks are ordered on one stream anyway.
+  struct AsyncSlot {
+    DevBuf<uint8_t>     dIn, dDesc;
+    DevBuf<orbx::KpRec> dKps;
+    DevBuf<int>         dCounts;
+    hipEvent_t          evIn = nullptr, evCompute = nullptr, evDone = nullptr;
+    uint8_t *           hIn = nullptr, *hOut = nullptr;  // pinned staging, only used when the caller's memory is pageable
+    size_t              hInCap = 0, hOutCap = 0;
+    int                 ticket = -1;  // ticket in flight (-1 = free)
+    int                 nframes = 0, cap = 0;
+    // deferred host copies out of hOut (pageable destinations)
+    orbx_keypoint_t*    uKps = nullptr;
+    uint8_t*            uDesc = nullptr;
+    int*                uCounts = nullptr;
+    bool                stagedOut = false;
+  };
+  static constexpr int kMaxAsyncDepth = 8;
+  AsyncSlot          slots[kMaxAsyncDepth];
+  int                asyncDepth = 3;
+  int                nextTicket = 0;
+  hipStream_t        sIn = nullptr, sOut = nullptr;
   static constexpr int kProfSlots = 32;  // ring of event sets: one per profiled batch
   hipEvent_t         ev[kProfSlots][ORBX_NUM_STAGES] = {};
   bool               evValid = false;
@@ -508,7 +533,7 @@ int orbx_extractor::run(const uint8_t* d_imgs, int B, int rows, int cols, size_t
   {
     const int nbPerFrame = (g.totalKp + kOdKpPerBlock - 1) / kOdKpPerBlock;
     hipLaunchKernelGGL(k_orient_describe, dim3(8 * ((B + 7) / 8) * nbPerFrame), dim3(256), 0, s, b, g, dPattern.p, d_counts, d_kps, d_desc, cap, B,
-                       nbPerFrame, getenv("ORBX_DBG_SKIP") ? atoi(getenv("ORBX_DBG_SKIP")) : 0);
+                       nbPerFrame, tapMode);
   }
   if (prof) {
     HIP_TRY(hipEventRecord(ev[6], s));
@@ -522,10 +547,13 @@ extern "C" {
 
 const char* orbx_last_error(void) { return g_err.c_str(); }
 
+// Not part of include/orbx.h: the matcher and vocabulary translation units report through the same per-thread slot.
+void orbx_internal_set_error(const char* s) { g_err = s ? s : ""; }
+
 int orbx_create(orbx_t** out, int nfeatures, float scale_factor, int nlevels, int ini_th_fast, int min_th_fast, int device_id) {
   if (!out) return -2;
   *out = nullptr;
-  if (nfeatures < 1 || nlevels < 1 || nlevels > orbx::kMaxLevels || !(scale_factor > 1.0f) || min_th_fast > ini_th_fast) {
+  if (nfeatures < 1 || nlevels < 1 || nlevels > orbx::kMaxLevels || !(scale_factor > 1.0f)) {
     g_err = "orbx_create: bad parameters";
     return -2;
   }
@@ -609,6 +637,18 @@ void orbx_destroy(orbx_t* h) {
   }
   if (h->hOut) hipHostFree(h->hOut);
   if (h->hIn) hipHostFree(h->hIn);
+  for (hipStream_t st : {h->sIn, h->sOut})
+    if (st) {
+      hipStreamSynchronize(st);
+      hipStreamDestroy(st);
+    }
+  for (auto& sl : h->slots) {
+    sl.dIn.release(), sl.dDesc.release(), sl.dKps.release(), sl.dCounts.release();
+    for (hipEvent_t e : {sl.evIn, sl.evCompute, sl.evDone})
+      if (e) hipEventDestroy(e);
+    if (sl.hIn) hipHostFree(sl.hIn);
+    if (sl.hOut) hipHostFree(sl.hOut);
+  }
   for (hipEvent_t e : {h->evFork, h->evJoin, h->evBlur0, h->evBlur1})
     if (e) hipEventDestroy(e);
   if (h->evValid)
@@ -641,6 +681,12 @@ void orbx_get_features_per_level(const orbx_t* h, int* out) {
 int orbx_set_input_resize(orbx_t* h, int new_cols, int new_rows) {
   if (!h || new_cols < 0 || new_rows < 0 || ((new_cols == 0) != (new_rows == 0))) return -2;
   h->preW = new_cols, h->preH = new_rows, h->preSrcW = h->preSrcH = 0;
+  return 0;
+}
+
+int orbx_set_tap_contraction(orbx_t* h, int mode) {
+  if (!h || mode < 0 || mode > 2) return -2;
+  h->tapMode = mode;
   return 0;
 }
 
@@ -748,6 +794,158 @@ int orbx_extract(orbx_t* h, const uint8_t* img, int rows, int cols, size_t step_
   }
   if (n_out) *n_out = n;
   return counts[1];
+}
+
+// ---- streaming form: host frames in, host records out, several chunks in flight --------------------------------------------
+void* orbx_host_alloc(size_t bytes) {
+  void* p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  return p;
+}
+
+void orbx_host_free(void* p) {
+  if (p) hipHostFree(p);
+}
+
+static bool is_pinned(const void* p) {
+  hipPointerAttribute_t attr;
+  if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+    (void)hipGetLastError();  // pageable memory: not an error for us
+    return false;
+  }
+  return attr.type == hipMemoryTypeHost;
+}
+
+int orbx_set_async_depth(orbx_t* h, int depth) {
+  if (!h || depth < 1 || depth > orbx_extractor::kMaxAsyncDepth) return -2;
+  for (auto& sl : h->slots)
+    if (sl.ticket >= 0) {
+      g_err = "orbx_set_async_depth: chunks are in flight";
+      return -2;
+    }
+  h->asyncDepth = depth;
+  return 0;
+}
+
+static int ensure_pinned(uint8_t** p, size_t* capBytes, size_t need) {
+  if (*capBytes >= need) return 0;
+  if (*p) hipHostFree(*p);
+  *p = nullptr, *capBytes = 0;
+  HIP_TRY(hipHostMalloc((void**)p, need, hipHostMallocDefault));
+  *capBytes = need;
+  return 0;
+}
+
+int orbx_extract_async(orbx_t* h, const uint8_t* imgs, int nframes, int rows, int cols, size_t step_bytes, size_t frame_stride_bytes, int lap0,
+                       int lap1, orbx_keypoint_t* kps, uint8_t* desc, int* counts, int cap, int* ticket) {
+  if (ticket) *ticket = -1;
+  if (!h || !ticket || nframes < 0) return -2;
+  if (!imgs || rows <= 0 || cols <= 0 || nframes == 0) return -1;
+  if (!kps || !desc || !counts || step_bytes < (size_t)cols || (nframes > 1 && frame_stride_bytes < step_bytes * (size_t)(rows - 1) + cols)) {
+    g_err = "orbx_extract_async: bad arguments";
+    return -2;
+  }
+  HIP_TRY(hipSetDevice(h->device));
+  int er, ec;
+  h->effective(rows, cols, &er, &ec);
+  int rc = h->makeGeometry(er, ec);
+  if (rc) return rc;
+  if (cap < h->geom.totalKp) {
+    g_err = "orbx_extract_async: cap below orbx_max_keypoints()";
+    return -2;
+  }
+  const int                  t  = h->nextTicket;
+  orbx_extractor::AsyncSlot& sl = h->slots[t % h->asyncDepth];
+  if (sl.ticket >= 0) {
+    g_err = "orbx_extract_async: all slots in flight (orbx_wait the oldest ticket first, or raise orbx_set_async_depth)";
+    return -2;
+  }
+  if (!h->sIn) {
+    HIP_TRY(hipStreamCreateWithFlags(&h->sIn, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&h->sOut, hipStreamNonBlocking));
+  }
+  if (!sl.evIn) {
+    HIP_TRY(hipEventCreateWithFlags(&sl.evIn, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&sl.evCompute, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&sl.evDone, hipEventDisableTiming));
+  }
+  const size_t inBytes = frame_stride_bytes * (size_t)(nframes - 1) + step_bytes * (size_t)(rows - 1) + cols;
+  const size_t nk = (size_t)nframes * cap;
+  if (sl.dIn.ensure(inBytes + 256) || sl.dKps.ensure(nk) || sl.dDesc.ensure(nk * 32) || sl.dCounts.ensure((size_t)nframes * 2)) return -3;
+  // upload: straight from the caller's memory when it is pinned (orbx_host_alloc / hipHostRegister), else through pinned staging
+  const uint8_t* hsrc = imgs;
+  if (!is_pinned(imgs)) {
+    rc = ensure_pinned(&sl.hIn, &sl.hInCap, inBytes);
+    if (rc) return rc;
+    memcpy(sl.hIn, imgs, inBytes);
+    hsrc = sl.hIn;
+  }
+  HIP_TRY(hipMemcpyAsync(sl.dIn.p, hsrc, inBytes, hipMemcpyHostToDevice, h->sIn));
+  HIP_TRY(hipEventRecord(sl.evIn, h->sIn));
+  HIP_TRY(hipStreamWaitEvent(h->stream, sl.evIn, 0));
+  rc = h->runResized(sl.dIn.p, nframes, rows, cols, step_bytes, frame_stride_bytes, lap0, lap1, sl.dKps.p, sl.dDesc.p, sl.dCounts.p, cap, h->stream);
+  if (rc) return rc;
+  HIP_TRY(hipEventRecord(sl.evCompute, h->stream));
+  // download of the fixed-capacity records
+  HIP_TRY(hipStreamWaitEvent(h->sOut, sl.evCompute, 0));
+  const size_t kpBytes = nk * sizeof(orbx_keypoint_t), dBytes = nk * 32, cBytes = (size_t)nframes * 2 * sizeof(int);
+  sl.stagedOut = !(is_pinned(kps) && is_pinned(desc) && is_pinned(counts));
+  if (sl.stagedOut) {
+    rc = ensure_pinned(&sl.hOut, &sl.hOutCap, kpBytes + dBytes + cBytes);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(sl.hOut, sl.dKps.p, kpBytes, hipMemcpyDeviceToHost, h->sOut));
+    HIP_TRY(hipMemcpyAsync(sl.hOut + kpBytes, sl.dDesc.p, dBytes, hipMemcpyDeviceToHost, h->sOut));
+    HIP_TRY(hipMemcpyAsync(sl.hOut + kpBytes + dBytes, sl.dCounts.p, cBytes, hipMemcpyDeviceToHost, h->sOut));
+  } else {
+    HIP_TRY(hipMemcpyAsync(kps, sl.dKps.p, kpBytes, hipMemcpyDeviceToHost, h->sOut));
+    HIP_TRY(hipMemcpyAsync(desc, sl.dDesc.p, dBytes, hipMemcpyDeviceToHost, h->sOut));
+    HIP_TRY(hipMemcpyAsync(counts, sl.dCounts.p, cBytes, hipMemcpyDeviceToHost, h->sOut));
+  }
+  HIP_TRY(hipEventRecord(sl.evDone, h->sOut));
+  sl.ticket = t, sl.nframes = nframes, sl.cap = cap, sl.uKps = kps, sl.uDesc = desc, sl.uCounts = counts;
+  h->nextTicket = t + 1;
+  *ticket = t;
+  return 0;
+}
+
+static orbx_extractor::AsyncSlot* find_slot(orbx_t* h, int ticket) {
+  if (!h || ticket < 0) return nullptr;
+  orbx_extractor::AsyncSlot& sl = h->slots[ticket % h->asyncDepth];
+  return sl.ticket == ticket ? &sl : nullptr;
+}
+
+int orbx_async_device_buffers(orbx_t* h, int ticket, const orbx_keypoint_t** d_kps, const uint8_t** d_desc, const int** d_counts, void** stream) {
+  orbx_extractor::AsyncSlot* sl = find_slot(h, ticket);
+  if (!sl) {
+    g_err = "orbx_async_device_buffers: unknown ticket";
+    return -2;
+  }
+  if (d_kps) *d_kps = (const orbx_keypoint_t*)sl->dKps.p;
+  if (d_desc) *d_desc = sl->dDesc.p;
+  if (d_counts) *d_counts = sl->dCounts.p;
+  if (stream) *stream = (void*)h->stream;
+  return 0;
+}
+
+int orbx_wait(orbx_t* h, int ticket) {
+  orbx_extractor::AsyncSlot* sl = find_slot(h, ticket);
+  if (!sl) {
+    g_err = "orbx_wait: unknown ticket";
+    return -2;
+  }
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipEventSynchronize(sl->evDone));
+  if (sl->stagedOut) {
+    const size_t nk = (size_t)sl->nframes * sl->cap, kpBytes = nk * sizeof(orbx_keypoint_t), dBytes = nk * 32;
+    memcpy(sl->uKps, sl->hOut, kpBytes);
+    memcpy(sl->uDesc, sl->hOut + kpBytes, dBytes);
+    memcpy(sl->uCounts, sl->hOut + kpBytes + dBytes, (size_t)sl->nframes * 2 * sizeof(int));
+  }
+  sl->ticket = -1;
+  return 0;
 }
 
 static int copy_level(orbx_t* h, const uint8_t* base, int pitch, int w, int hgt, uint8_t* dst, size_t dst_step, int* rows, int* cols) {

@@ -548,7 +548,7 @@ __global__ __launch_bounds__(kFastThreads, TS <= 52 ? 8 : 5) void k_fast_cells(B
             for (int dx = -1; dx <= 1; dx++)
               if (dx | dy) {
                 const int t = score[(y + dy) * ts + x + dx];
-                m2          = max(m2, t);
+                m2          = max(m2, t >= minTh ? t : 0);  // (minThFAST may exceed iniThFAST: the reference does not check)
                 m1          = max(m1, t >= iniTh ? t : 0);
               }
           f1 = (s >= iniTh && s > m1);
@@ -1018,7 +1018,7 @@ __constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9
 constexpr int kOdKpPerBlock = 8;  // two keypoints per wave (one per 32-lane half), four waves
 
 __global__ __launch_bounds__(256, 6) void k_orient_describe(Bufs b, FrameGeom g, const PatternTab* __restrict__ pat, const int* counts,
-                                                          KpRec* kps, uint8_t* desc, int cap, int nframes, int nbPerFrame, int dbgSkip) {
+                                                          KpRec* kps, uint8_t* desc, int cap, int nframes, int nbPerFrame, int tapMode) {
   // 1-D grid with frame -> XCD affinity: all workgroups of frame f run on XCD f % 8 (blocks b, b + 8, ... share an
   // L2), so the raw + blurred levels of a frame (1.9 MB at VGA) are pulled into ONE 4-MiB L2 instead of all eight.
   // A keypoint is a short chain of dependent steps (info -> pixels -> angle -> taps), so the kernel is bound by latency x
@@ -1123,8 +1123,18 @@ __global__ __launch_bounds__(256, 6) void k_orient_describe(Bufs b, FrameGeom g,
   for (int w = 0; w < 8; w++) {
     const char4 p4 = __builtin_bit_cast(char4, sPat[w * 32 + hl]);
     const float x0 = (float)p4.x, y0 = (float)p4.y, x1 = (float)p4.z, y1 = (float)p4.w;
-    const int   r0 = __float2int_rn(x0 * bb + y0 * a), c0 = __float2int_rn(x0 * a - y0 * bb);
-    const int   r1 = __float2int_rn(x1 * bb + y1 * a), c1 = __float2int_rn(x1 * a - y1 * bb);
+    // tap rotation as the reference's compiler evaluates it (include/orbx.h: orbx_set_tap_contraction; wave-uniform switch)
+    int r0, c0, r1, c1;
+    if (tapMode == 1) {  // g++ -O3 -march=native on an FMA host: fma(x, b, y * a), fma(x, a, -(y * b))
+      r0 = __float2int_rn(__fmaf_rn(x0, bb, y0 * a)), c0 = __float2int_rn(__fmaf_rn(x0, a, -(y0 * bb)));
+      r1 = __float2int_rn(__fmaf_rn(x1, bb, y1 * a)), c1 = __float2int_rn(__fmaf_rn(x1, a, -(y1 * bb)));
+    } else if (tapMode == 2) {  // the other contraction: fma(y, a, x * b), fma(-y, b, x * a)
+      r0 = __float2int_rn(__fmaf_rn(y0, a, x0 * bb)), c0 = __float2int_rn(__fmaf_rn(-y0, bb, x0 * a));
+      r1 = __float2int_rn(__fmaf_rn(y1, a, x1 * bb)), c1 = __float2int_rn(__fmaf_rn(-y1, bb, x1 * a));
+    } else {  // no contraction
+      r0 = __float2int_rn(x0 * bb + y0 * a), c0 = __float2int_rn(x0 * a - y0 * bb);
+      r1 = __float2int_rn(x1 * bb + y1 * a), c1 = __float2int_rn(x1 * a - y1 * bb);
+    }
     const int   t0 = bl[r0 * bp + c0], t1 = bl[r1 * bp + c1];
     const unsigned long long bal = __ballot(t0 < t1);
     const uint32_t           wv  = half ? (uint32_t)(bal >> 32) : (uint32_t)bal;

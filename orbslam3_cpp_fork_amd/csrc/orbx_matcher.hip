@@ -46,7 +46,11 @@ constexpr int      kGridCols = 64, kGridRows = 48;  // FRAME_GRID_COLS / ROWS (i
   } while (0)
 
 thread_local std::string g_merr;
-void                     set_err(const std::string& s) { g_merr = s; }
+extern "C" void          orbx_internal_set_error(const char* s);  // orbx_extractor.hip: the slot orbx_last_error() reads
+void                     set_err(const std::string& s) {
+  g_merr = s;
+  orbx_internal_set_error(s.c_str());  // one message slot per thread for the whole library (include/orbx.h)
+}
 
 __device__ __forceinline__ int hamming256(const uint4& a0, const uint4& a1, const uint8_t* __restrict__ p) {
   const uint4 b0 = *reinterpret_cast<const uint4*>(p);
@@ -1226,7 +1230,7 @@ struct Arena {
   uint8_t *h = nullptr, *d = nullptr;
   size_t   cap = 0, off = 0;
   int      reserve(size_t bytes) {
-    off = 0;
+    off = 0, overflow = false;
     if (bytes <= cap) return 0;
     release();
     if (hipHostMalloc((void**)&h, bytes, hipHostMallocDefault) != hipSuccess || hipMalloc((void**)&d, bytes) != hipSuccess) {
@@ -1242,13 +1246,23 @@ struct Arena {
     if (d) hipFree(d);
     h = d = nullptr, cap = off = 0;
   }
+  bool overflow = false;  // a put() did not fit: checked by the caller after the last put (ok())
   template <class T>
   T* put(const T* src, size_t n) {  // returns the DEVICE address; src == NULL just reserves
     off   = (off + 15) & ~(size_t)15;
     T* dp = reinterpret_cast<T*>(d + off);
+    if (off + n * sizeof(T) > cap) {  // never write past the reservation: the caller's byte budget was wrong
+      overflow = true;
+      return reinterpret_cast<T*>(d);
+    }
     if (src && n) memcpy(h + off, src, n * sizeof(T));
     off += n * sizeof(T);
     return dp;
+  }
+  bool ok() {
+    if (!overflow) return true;
+    set_err("internal: staging arena budget exceeded");
+    return false;
   }
   template <class T>
   const T* host_of(const T* dev_ptr) const { return reinterpret_cast<const T*>(h + (reinterpret_cast<const uint8_t*>(dev_ptr) - d)); }
@@ -1267,6 +1281,8 @@ struct orbm_matcher {
 };
 
 extern "C" {
+
+const char* orbm_last_error(void) { return g_merr.c_str(); }
 
 int orbm_create(orbm_t** out, int device_id) {
   if (!out) return -2;
@@ -1449,9 +1465,11 @@ int orbm_match_groups(orbm_t* h, const uint8_t* q, int nq, const uint8_t* t, int
     a.q_off = in.put(q_off, ngroups + 1), a.t_off = in.put(t_off, ngroups + 1);
     a.q_idx = in.put(q_idx, nqe), a.t_idx = in.put(t_idx, nte);
   }
+  if (!in.ok() || !h->out.ok()) return -3;
   if (in.off) HIP_TRYM(hipMemcpyAsync(in.d, in.h, in.off, hipMemcpyHostToDevice, s));
   Arena& out = h->out;
   a.nmatches = out.put((const int*)nullptr, 4), a.match_t_of_q = out.put((const int*)nullptr, nq), a.match_q_of_t = out.put((const int*)nullptr, nt);
+  if (!out.ok()) return -3;
   a.nq = nq, a.nt = nt, a.ngroups = ngroups, a.nqe = nqe, a.q_astride = 1, a.t_astride = 1;
   a.th = th, a.strict_lt = strict_lt, a.check_ori = check_ori, a.ratio = ratio, a.dstar = prune_bound(th, ratio);
   a.topk = h->topk.p, a.nvalid = h->nvalid.p, a.binOf = h->binOf.p;
@@ -1711,7 +1729,7 @@ static int proj_single(orbm_t* h, int mode, const float* inv_sigma2, const float
       }
   }
   hipStream_t  s  = h->stream;
-  const size_t inBytes = (size_t)n1 * (32 + 8 + 4 + 4 + 4 + 4 + 1) + (size_t)n2 * (32 + sizeof(orbx_keypoint_t) + 4 + 1) + (size_t)ng * 6 + 64 * 4 + 16 * 16;
+  const size_t inBytes = (size_t)n1 * (32 + 8 + 4 + 4 + 4 + 4 + 1) + (size_t)n2 * (32 + sizeof(orbx_keypoint_t) + 4 + 1) + (size_t)ng * 6 + (size_t)2 * nlevels * 4 + 16 * 24;
   const size_t outBytes = (size_t)(n1 + n2 + 4) * 4 + 64;
   if (h->in.reserve(inBytes) || h->out.reserve(outBytes) || h->topk.ensure((size_t)(n1 + 1) * kTopK) || h->nvalid.ensure(n1 + 1) ||
       h->binOf.ensure(n1 + 1))
@@ -1731,9 +1749,11 @@ static int proj_single(orbm_t* h, int mode, const float* inv_sigma2, const float
   }
   a.sf = in.put(scale_factors, nlevels), a.uRight = cur_u_right ? in.put(cur_u_right, n2) : nullptr, a.oct1 = in.put(last_octave, n1);
   a.valid1 = last_valid ? in.put(last_valid, n1) : nullptr, a.occupied = cur_occupied ? in.put(cur_occupied, n2) : nullptr;
+  if (!in.ok() || !h->out.ok()) return -3;
   HIP_TRYM(hipMemcpyAsync(in.d, in.h, in.off, hipMemcpyHostToDevice, s));
   Arena& out = h->out;
   a.nmatches = out.put((const int*)nullptr, 4), a.m12 = out.put((const int*)nullptr, n1), a.m21 = out.put((const int*)nullptr, n2);
+  if (!out.ok()) return -3;
   a.n1 = n1, a.n2 = n2, a.ng = ng, a.th = th, a.mbf = mbf, a.minX = min_x, a.minY = min_y, a.gwInv = gwInv, a.ghInv = ghInv, a.dir = dir;
   a.thDist = th_dist, a.check_ori = check_ori, a.topk = h->topk.p, a.nvalid = h->nvalid.p, a.binOf = h->binOf.p;
   if (n1 > 0) hipLaunchKernelGGL(k_proj_topk, dim3((n1 + 3) / 4), dim3(256), 0, s, a);
@@ -1911,9 +1931,11 @@ int orbm_search_for_triangulation(orbm_t* h, const uint8_t* d1, const orbx_keypo
   a.sf = in.put(scale_factors, nlevels), a.sigma2 = level_sigma2 ? in.put(level_sigma2, nlevels) : nullptr;
   for (int i = 0; i < 9; i++) a.F[i] = F12 ? F12[i] : 0.f;
   a.ep[0] = ep[0], a.ep[1] = ep[1];
+  if (!in.ok() || !h->out.ok()) return -3;
   HIP_TRYM(hipMemcpyAsync(in.d, in.h, in.off, hipMemcpyHostToDevice, s));
   Arena& out = h->out;
   a.nmatches = out.put((const int*)nullptr, 4), a.m12 = out.put((const int*)nullptr, n1);
+  if (!out.ok()) return -3;
   a.n1 = n1, a.nqe = nqe, a.onlyStereo = only_stereo, a.coarse = coarse, a.th = th_low, a.check_ori = check_ori, a.binOf = h->binOf.p;
   if (n1) HIP_TRYM(hipMemsetAsync(a.m12, 0xff, (size_t)n1 * 4, s));
   if (nqe > 0) hipLaunchKernelGGL(k_tri_search, dim3((nqe + 3) / 4), dim3(256), 0, s, a);

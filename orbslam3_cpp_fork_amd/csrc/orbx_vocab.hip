@@ -30,7 +30,11 @@
 namespace {
 
 thread_local std::string g_verr;
-void                     set_verr(const std::string& s) { g_verr = s; }
+extern "C" void          orbx_internal_set_error(const char* s);  // orbx_extractor.hip: the slot orbx_last_error() reads
+void                     set_verr(const std::string& s) {
+  g_verr = s;
+  orbx_internal_set_error(s.c_str());
+}
 
 #define HIP_TRYV(expr)                                                       \
   do {                                                                       \

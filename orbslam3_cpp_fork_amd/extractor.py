@@ -63,6 +63,10 @@ class ORBextractor:
         """cv::resize(im, im, Size(new_cols, new_rows)) of System::Track* (src/System.cc:472-478) fused in front of the extractor; 0, 0 = off."""
         check(_lib.lib().orbx_set_input_resize(self._h, int(new_cols), int(new_rows)), "orbx_set_input_resize")
 
+    def set_tap_contraction(self, mode):
+        """Tap-rotation evaluation of computeOrbDescriptor (include/orbx.h): 1 = reference as built on an FMA host (default), 0 = none, 2 = other."""
+        check(_lib.lib().orbx_set_tap_contraction(self._h, int(mode)), "orbx_set_tap_contraction")
+
     def max_keypoints(self, rows, cols):
         return check(_lib.lib().orbx_max_keypoints(self._h, rows, cols), "orbx_max_keypoints")
 
@@ -97,6 +101,31 @@ class ORBextractor:
             ),
             "orbx_extract_batch_device",
         )
+
+    # ---- streaming form (host frames in, host records out, several chunks in flight)
+    def set_async_depth(self, depth):
+        check(_lib.lib().orbx_set_async_depth(self._h, int(depth)), "orbx_set_async_depth")
+
+    def extract_async(self, imgs, kps, desc, counts, cap, vLappingArea=(0, 0)):
+        """imgs: uint8 [nframes, rows, cols] host array (pinned_array() memory is read by DMA directly); kps / desc / counts: host
+        arrays [nframes, cap] KP_DTYPE, [nframes, cap, 32] uint8, [nframes, 2] int32 that hold the results after wait(ticket)."""
+        nframes, rows, cols = imgs.shape
+        t = C.c_int(-1)
+        check(
+            _lib.lib().orbx_extract_async(self._h, ptr(imgs), nframes, rows, cols, imgs.strides[1], imgs.strides[0], int(vLappingArea[0]), int(vLappingArea[1]),
+                                          ptr(kps), ptr(desc), ptr(counts), cap, C.byref(t)),
+            "orbx_extract_async",
+        )
+        return t.value
+
+    def async_device_buffers(self, ticket):
+        """(d_kps, d_desc, d_counts, stream) raw device pointers / hipStream_t of a ticket in flight."""
+        a, b, c, s = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        check(_lib.lib().orbx_async_device_buffers(self._h, ticket, C.byref(a), C.byref(b), C.byref(c), C.byref(s)), "orbx_async_device_buffers")
+        return a.value, b.value, c.value, s.value
+
+    def wait(self, ticket):
+        check(_lib.lib().orbx_wait(self._h, ticket), "orbx_wait")
 
     # ---- mvImagePyramid (include/ORBextractor.h:87)
     def _level(self, fn, frame, level):
@@ -143,6 +172,30 @@ class ORBextractor:
         ms = np.zeros(_lib.NUM_STAGES, np.float32)
         check(_lib.lib().orbx_get_stage_ms(self._h, ptr(ms)), "orbx_get_stage_ms")
         return dict(zip(_lib.STAGE_NAMES, ms.tolist()))
+
+
+def pinned_array(shape, dtype):
+    """numpy array over orbx_host_alloc memory (page-locked: the streaming entry points DMA straight from / into it).  The
+    memory is released when the array (and every view of it) is gone."""
+    dt = np.dtype(dtype)
+    n = int(np.prod(shape)) * dt.itemsize
+    p = _lib.lib().orbx_host_alloc(max(n, 1))
+    if not p:
+        raise OrbxError("orbx_host_alloc(%d) failed" % n)
+
+    class _Owner:
+        def __init__(self, p):
+            self.p = p
+
+        def __del__(self):
+            try:
+                _lib.lib().orbx_host_free(C.c_void_p(self.p))
+            except Exception:
+                pass
+
+    buf = (C.c_uint8 * max(n, 1)).from_address(p)
+    buf._owner = _Owner(p)
+    return np.frombuffer(buf, dtype=dt, count=int(np.prod(shape))).reshape(shape)
 
 
 def UndistortKeyPoints(ex, keys, K, dist):

@@ -26,8 +26,13 @@ for lap in ((0, 1000), (0, 0)):
     for f in range(2):
         rc, k, d = ex(frames[f], lap)
         res.append((rc, k, d))
+ex.set_tap_contraction(0)  # the un-contracted tap rotation (include/orbx.h: orbx_set_tap_contraction); keypoints are unaffected
+_, k_nf, d_nf = ex(frames[0], (0, 1000))
+ex.set_tap_contraction(1)
+assert (k_nf.view(np.uint32) == res[0][1].view(np.uint32)).all()
 np.savez_compressed(
     os.path.join(out, "extract_320x240_500.npz"),
+    desc_nofma_lap1000_f0=d_nf,
     frames=frames, params=np.array([500, 8, 20, 7], np.int32), scale=np.float32(1.2),
     mono_lap1000_f0=res[0][0], kps_lap1000_f0=res[0][1], desc_lap1000_f0=res[0][2],
     mono_lap1000_f1=res[1][0], kps_lap1000_f1=res[1][1], desc_lap1000_f1=res[1][2],
