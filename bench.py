@@ -1,18 +1,27 @@
 #!/usr/bin/env python3
 """bench.py -- frames/s of the ORB extract + match hot path on MI355X (BASELINE.json metric).
 
-Workload at N = 1 (BASELINE.json configs[1] + the matching half of the metric): a synthetic 640x480 8-bit
-camera stream, ORBextractor(1000 features, 1.2, 8 levels, iniThFAST 20, minThFAST 7), every frame matched
-against its predecessor with the brute-force SearchByBoW loop (TH_LOW 50, ratio 0.7, rotation check).
-A "step" = one chunk of --frames frames already resident in HBM: 6 extractor kernels classes + 2 matcher
-kernels over the whole chunk.  With N > 1 every rank runs the same chunk size on its own camera (weak
-scaling, the path shards by frame) and the keypoints/descriptors are gathered to rank 0 over RCCL.
+Workload at N = 1 (BASELINE.json configs[1] + the matching half of the metric): a synthetic 640x480 8-bit camera stream,
+ORBextractor(1000 features, 1.2, 8 levels, iniThFAST 20, minThFAST 7), every frame matched against its predecessor with the
+brute-force SearchByBoW loop (TH_LOW 50, ratio 0.7, rotation check).  A "step" = one chunk of --frames frames.
 
-Prints ONE JSON line (rank 0).  `value` = frames of all ranks / max-over-ranks wall time of the timed steps.
+Two figures come out of one run:
+  value           chunks already resident in HBM when the timed region starts (the contract's definition);
+  pcie_inclusive  the same steps fed from pinned HOST memory through the streaming ABI (orbx_extract_async / orbx_wait): the timed
+                  region contains the H2D copy of every frame and the D2H copy of every keypoint / descriptor / match record,
+                  three chunks in flight (upload k + 1 || kernels k || download k - 1).  Never reported as `value`.
+
+N > 1: `python bench.py --gpus N` starts N ranks itself (child processes, before anything touches the GPU) unless a launcher
+(torch.distributed.run) already did; one rank per GPU over RCCL; fails non-zero when fewer than N devices or ranks exist.  Stream
+workloads give every rank its own camera (weak scaling); the rig workload (BASELINE config 5) deals 8 cameras of 1920x1080 over the
+ranks (strong scaling); the stereo workload gives every rank its own pairs.  The one exchange step is the gather of the fixed-capacity
+records to rank 0.  Prints ONE JSON line (rank 0); `value` = units of all ranks / max-over-ranks wall time of the timed steps.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -22,15 +31,20 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+PCIE_PEAK_GBS = 63.0   # PCIe Gen5 x16 spec (same guide)
+# wave64 VALU instruction = 2 cycles on a SIMD-32 (same guide, "Wave scheduling"): 256 CUs x 4 SIMDs x 2.4 GHz / 2
+VALU_PEAK_GINST = 256 * 4 * 2.4 / 2
 
 WORKLOADS = {
     # name: (rows, cols, nfeatures)
     "vga_stream_640x480_8lvl_1000feat_extract+match": (480, 640, 1000),
     "euroc_stream_752x480_8lvl_1000feat_extract+match": (480, 752, 1000),
-    "rig_1920x1080_8lvl_1000feat_extract+match": (1080, 1920, 1000),
+    # BASELINE config 5: 8 cameras, dealt over the ranks (8 / N cameras per GPU)
+    "rig_8cam_1920x1080_8lvl_1000feat_extract+match": (1080, 1920, 1000),
     # BASELINE config 4: stereo pairs, two extractor handles per step, lapping {0, 0}, then Frame::ComputeStereoMatches
     "kitti_stereo_1241x376_8lvl_2000feat_extract+stereo": (376, 1241, 2000),
 }
+RIG_CAMERAS = 8
 
 
 def level_sizes(rows, cols, nlevels=8, scale=1.2):
@@ -57,53 +71,251 @@ def algorithmic_bytes(rows, cols, nfeatures, nlevels=8):
     }
 
 
-def cpu_baseline(frames, nfeatures, budget_s=12.0):
-    """Single-thread CPU restatement (oracle/, kind "port") on a bounded sample of the same stream."""
+# ------------------------------------------------------------------------------------------------------------------------------
+# CPU baseline: the oracle = this repository's single-thread restatement of the reference path
+# ------------------------------------------------------------------------------------------------------------------------------
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _pct(a, q):
+    return float(np.percentile(np.asarray(a), q))
+
+
+def cpu_baseline(frames, nfeatures, lap=(0, 1000), warm=20, timed=400, stereo=None):
+    """One pinned thread, `warm` untimed frames then `timed` frames of the same synthetic stream; per-frame wall time around the
+    operator() call alone (what REGISTER_TIMES brackets, src/Frame.cc:448-459) and around extract + match; then an all-cores run
+    (one frame per thread at a time) for context.  stereo = (L, R, mb, mbf): a unit is a stereo pair (two extractions + stereo matches)."""
     from oracle import oracle_py as O
 
-    ex = O.OracleExtractor(nfeatures, 1.2, 8, 20, 7)
-    prev = None
-    rc, k, d = ex(frames[-1], (0, 1000))  # warm-up + predecessor of frame 0 (the GPU step wraps around the same way)
-    prev = (k, d)
+    native = O.select_native()  # -march=native build made on this very host (falls back to the portable x86-64-v3 build)
+    cores = sorted(os.sched_getaffinity(0))
+    old = set(cores)
+    pin = cores[len(cores) // 2]
+    os.sched_setaffinity(0, {pin})
+    try:
+        if stereo is None:
+            ex = O.OracleExtractor(nfeatures, 1.2, 8, 20, 7)
+
+            def unit(i, prev):
+                f = i % len(frames)
+                t0 = time.perf_counter()
+                rc, k, d = ex(frames[f], lap)
+                t1 = time.perf_counter()
+                if prev is not None:
+                    O.match_groups(prev[1], d, prev[0]["angle"], k["angle"], th=50, ratio=0.7, strict_lt=False, check_ori=True)
+                t2 = time.perf_counter()
+                return (k, d), t1 - t0, t2 - t0
+        else:
+            L, R, mb, mbf = stereo
+            ol, orr = O.OracleExtractor(nfeatures), O.OracleExtractor(nfeatures)
+
+            def unit(i, prev):
+                f = i % len(L)
+                t0 = time.perf_counter()
+                _, a, da = ol(L[f], (0, 0))
+                t1 = time.perf_counter()
+                _, b, db = orr(R[f], (0, 0))
+                O.stereo_matches(ol, orr, a, da, b, db, mb, mbf)
+                t2 = time.perf_counter()
+                return None, t1 - t0, t2 - t0
+
+        prev = None
+        for i in range(warm):
+            prev, _, _ = unit(i, prev)
+        te, tu = [], []
+        for i in range(warm, warm + timed):
+            prev, a, b = unit(i, prev)
+            te.append(a * 1e3)
+            tu.append(b * 1e3)
+    finally:
+        os.sched_setaffinity(0, old)
+    # all-cores context run: one extractor per thread, frames in parallel (the oracle calls release the GIL)
+    import threading
+
+    nthr = len(cores)
+    per = max(8, min(60, timed // 4))
+    done = [0] * nthr
+
+    def worker(t):
+        if stereo is None:
+            e = O.OracleExtractor(nfeatures, 1.2, 8, 20, 7)
+            pv = None
+            for i in range(per + 2):
+                rc, k, d = e(frames[(t * 7 + i) % len(frames)], lap)
+                if pv is not None:
+                    O.match_groups(pv[1], d, pv[0]["angle"], k["angle"], th=50, ratio=0.7, strict_lt=False, check_ori=True)
+                pv = (k, d)
+                done[t] += 1
+        else:
+            L, R, mb, mbf = stereo
+            a_, b_ = O.OracleExtractor(nfeatures), O.OracleExtractor(nfeatures)
+            for i in range(per + 2):
+                f = (t * 7 + i) % len(L)
+                _, a, da = a_(L[f], (0, 0))
+                _, b, db = b_(R[f], (0, 0))
+                O.stereo_matches(a_, b_, a, da, b, db, mb, mbf)
+                done[t] += 1
+
+    thr = [threading.Thread(target=worker, args=(t,)) for t in range(nthr)]
     t0 = time.perf_counter()
-    done = 0
-    while time.perf_counter() - t0 < budget_s:
-        f = done % len(frames)
-        rc, k, d = ex(frames[f], (0, 1000))
-        O.match_groups(prev[1], d, prev[0]["angle"], k["angle"], th=50, ratio=0.7, strict_lt=False, check_ori=True)
-        prev = (k, d)
-        done += 1
-    dt = time.perf_counter() - t0
+    for t in thr:
+        t.start()
+    for t in thr:
+        t.join()
+    dt_all = time.perf_counter() - t0
+    unit_name = "frames/s" if stereo is None else "pairs/s"
+    what = "extract + match vs previous frame" if stereo is None else "two extractions + ComputeStereoMatches"
     return {
-        "value": round(done / dt, 3),
-        "unit": "frames/s",
+        "value": round(1e3 / _pct(tu, 50), 3),
+        "unit": unit_name,
         "cores": 1,
         "kind": "port",
-        "sample": "%d frames of the same synthetic stream, extract + match vs previous frame, oracle/orb_oracle.cpp single thread (-O3 -march=x86-64-v3 -ffp-contract=off), %.1f s" % (done, dt),
+        "sample": ("%d units of the same synthetic input after %d warm-up, %s per unit, oracle/orb_oracle.cpp (this repository's scalar restatement of the "
+                   "reference path; -O3 -march=%s -ffp-contract=off), ONE thread pinned to core %d; value = 1 / median. CAVEAT: the real reference links "
+                   "OpenCV's SIMD-dispatched FAST / resize / GaussianBlur and may be faster than this scalar port; no OpenCV exists on this box to time it."
+                   % (timed, warm, what, "native" if native else "x86-64-v3", pin)),
+        "ms_per_unit": {"median": round(_pct(tu, 50), 4), "p10": round(_pct(tu, 10), 4), "p90": round(_pct(tu, 90), 4)},
+        "ms_operator_call_only": {"median": round(_pct(te, 50), 4), "p10": round(_pct(te, 10), 4), "p90": round(_pct(te, 90), 4)},
+        "all_cores": {"value": round(sum(done) / dt_all, 2), "unit": unit_name, "threads": nthr, "units": sum(done)},
+        "cpu_model": _cpu_model(),
+        "nproc": nthr,
     }
 
 
-def run_stereo(args, rows, cols, nfeat):
-    """Config 4 (single GPU): step = B stereo pairs: extract left, extract right (two handles), ComputeStereoMatches for every pair."""
+# ------------------------------------------------------------------------------------------------------------------------------
+# process set-up
+# ------------------------------------------------------------------------------------------------------------------------------
+def self_launch(args, argv):
+    """--gpus N without a launcher: start the N ranks as child processes.  Nothing in this process has touched the GPU
+    (torch.cuda.device_count() does not initialise it), and the children are fresh interpreters."""
+    n = args.gpus
+    backend = os.environ.get("ORBX_DIST_BACKEND", "nccl")
     import torch
 
-    from orbslam3_cpp_fork_amd import _lib, synth
+    ndev = torch.cuda.device_count()
+    share = backend != "nccl" and os.environ.get("ORBX_SHARE_GPU") == "1"  # rehearsal of the control flow on a one-GPU box (gloo)
+    if ndev < n and not share:
+        sys.stderr.write("bench.py: --gpus %d but only %d device(s) visible\n" % (n, ndev))
+        sys.exit(3)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    rc = 0
+    alive = list(procs)
+    while alive:
+        for p in list(alive):
+            r = p.poll()
+            if r is None:
+                continue
+            alive.remove(p)
+            if r != 0 and rc == 0:
+                rc = r
+                for q in alive:  # a rank failed: the others would wait in a collective for ever
+                    q.terminate()
+        time.sleep(0.05)
+    sys.exit(rc)
+
+
+class Ctx:
+    pass
+
+
+def setup(args):
+    import torch
+    import torch.distributed as dist
+
+    c = Ctx()
+    c.rank = int(os.environ.get("RANK", "0"))
+    c.world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != c.world:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, c.world))
+    # "nccl" IS RCCL on ROCm.  ORBX_DIST_BACKEND=gloo (+ ORBX_SHARE_GPU=1) lets the multi-rank control flow be rehearsed on a one-GPU
+    # box (RCCL refuses two ranks on one device); the gather then stages through host memory.
+    c.backend = os.environ.get("ORBX_DIST_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if ndev < 1:
+        raise SystemExit("bench.py: no GPU visible (there is no CPU fallback)")
+    if c.world > ndev and not (c.backend != "nccl" and os.environ.get("ORBX_SHARE_GPU") == "1"):
+        raise SystemExit("bench.py: %d ranks but only %d device(s) visible" % (c.world, ndev))
+    c.local_rank = local_rank % ndev
+    torch.cuda.set_device(c.local_rank)
+    c.dev = torch.device("cuda", c.local_rank)
+    if c.world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if c.backend == "nccl":
+            dist.init_process_group("nccl", rank=c.rank, world_size=c.world, device_id=c.dev)
+        else:
+            dist.init_process_group(c.backend, rank=c.rank, world_size=c.world)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit("bench.py: the process group has %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus))
+    c.torch, c.dist = torch, dist
+    return c
+
+
+def max_over_ranks(c, dt):
+    if c.world == 1:
+        return dt
+    t = c.torch.tensor([dt], dtype=c.torch.float64, device=c.dev if c.backend == "nccl" else "cpu")
+    c.dist.all_reduce(t, op=c.dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def fence(c, lanes=()):
+    for ln in lanes:
+        ln.drain()
+    if c.world > 1:
+        c.dist.barrier()
+    c.torch.cuda.synchronize()
+
+
+def profile_summaries():
+    """Committed profile summaries of THIS command (tools/collect_profiles.sh): bench.py cannot read hardware counters itself, so the
+    HBM traffic and the VALU utilisation in the JSON line are those of the profiled run, tagged with their source file."""
+    out = {}
+    for key, name in (("pmc", "r02_pmc_summary.json"), ("valu", "r02_valu_summary.json")):
+        try:
+            out[key] = (name, json.load(open(os.path.join(ROOT, "profiles", name))))
+        except Exception:
+            out[key] = None
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# stereo workload (config 4)
+# ------------------------------------------------------------------------------------------------------------------------------
+def run_stereo(args, c, rows, cols, nfeat):
+    """step = B stereo pairs per rank: extract left, extract right (two handles), ComputeStereoMatches for every pair."""
+    torch = c.torch
+    from orbslam3_cpp_fork_amd import _lib, shard, synth
     from orbslam3_cpp_fork_amd.extractor import ORBextractor
 
     B = min(args.frames, 128)
-    dev = torch.device("cuda", 0)
-    pairs = [synth.make_stereo_pair(rows, cols, camera_idx=i % 8, frame_idx=i // 8) for i in range(B)]
+    dev = c.dev
+    pairs = [synth.make_stereo_pair(rows, cols, camera_idx=(i + c.rank) % 8, frame_idx=i // 8 + 100 * c.rank) for i in range(B)]
     L, R = np.stack([p[0] for p in pairs]), np.stack([p[1] for p in pairs])
     ts = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(ts)
     st = ts.cuda_stream
     dL, dR = torch.from_numpy(L).to(dev), torch.from_numpy(R).to(dev)
-    gl, gr = ORBextractor(nfeat), ORBextractor(nfeat)
+    gl, gr = ORBextractor(nfeat, device=c.local_rank), ORBextractor(nfeat, device=c.local_rank)
     cap = gl.max_keypoints(rows, cols)
     z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)
     kl, kr, dl, dr = z((B, cap, 7), torch.float32), z((B, cap, 7), torch.float32), z((B, cap, 32), torch.uint8), z((B, cap, 32), torch.uint8)
     cl, cr, ur, dp, kept = z((B, 2), torch.int32), z((B, 2), torch.int32), z((B, cap), torch.float32), z((B, cap), torch.float32), z(B, torch.int32)
     mb, mbf = 0.5372, 386.1448  # KITTI 00-02
+    gather = shard.RecordGather(B, cap, dev, c.world, c.rank, host_staged=(c.backend != "nccl")) if c.world > 1 else None
     ev = []
 
     def step(timed=False):
@@ -118,57 +330,57 @@ def run_stereo(args, rows, cols, nfeat):
         if timed:
             e1.record()
             ev.append((e0, e1))
+        if gather is not None:
+            gather(kl, dl, cl)  # left-eye records to rank 0 (synchronous on this stream; 15 MB per rank per step)
 
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
+    fence(c)
     gl.set_profiling(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(timed=True)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    fence(c)
+    dt = max_over_ranks(c, time.perf_counter() - t0)
+    if c.rank != 0:
+        return
     stage = gl.stage_ms()
     stage["stereo_matches"] = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-    value = B * args.steps / dt
+    value = B * args.steps * c.world / dt
     ab = algorithmic_bytes(rows, cols, nfeat)
+    dom = max(("pyramid", "fast", "octree", "blur", "orient_describe"), key=lambda k: stage[k])
+    per_frame = ab.get(dom, ab["output"])
+    achieved = per_frame * B / (stage[dom] * 1e-3) / 1e9
     out = {
-        "metric": "stereo pairs/s ORB extract x2 + ComputeStereoMatches (1241x376, 8 lvl, 2000 feat)", "value": round(value, 2), "unit": "pairs/s", "n_gpus": 1,
+        "metric": "stereo pairs/s ORB extract x2 + ComputeStereoMatches (1241x376, 8 lvl, 2000 feat)", "value": round(value, 2), "unit": "pairs/s", "n_gpus": c.world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u8", "data": "synthetic",
-        "config": {"workload": args.workload, "pairs_per_step": B, "rows": rows, "cols": cols, "nfeatures": nfeat, "nlevels": 8,
+        "config": {"workload": args.workload, "pairs_per_step_per_gpu": B, "rows": rows, "cols": cols, "nfeatures": nfeat, "nlevels": 8,
+                   "parallelism": "stereo pairs sharded over %d rank(s)%s" % (c.world, ", RCCL gather of the left-eye records to rank 0" if c.world > 1 else ""),
                    "keypoints_per_eye": float(cl[:, 0].float().mean()), "stereo_matches_per_pair": float(kept.float().mean())},
-        "roofline": {"bound": "hbm", "kernel": "k_fast_cells", "achieved": round(ab["fast"] * B / (stage["fast"] * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(ab["fast"] * B / (stage["fast"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), "traffic": None,
-                     "algorithmic_bytes_per_launch": ab["fast"] * B, "avg_launch_ms": round(stage["fast"], 5)},
+        "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                     "algorithmic_bytes_per_launch": per_frame * B, "avg_launch_ms": round(stage[dom], 5)},
         "stage_ms_left_eye": {k: round(v, 5) for k, v in stage.items()},
     }
-    if not args.no_cpu_baseline:
-        from oracle import oracle_py as O
-
-        ol, orr = O.OracleExtractor(nfeat), O.OracleExtractor(nfeat)
-        t0, done = time.perf_counter(), 0
-        while time.perf_counter() - t0 < 12.0:
-            f = done % B
-            _, a, da = ol(L[f], (0, 0))
-            _, b, db = orr(R[f], (0, 0))
-            O.stereo_matches(ol, orr, a, da, b, db, mb, mbf)
-            done += 1
-        dtc = time.perf_counter() - t0
-        out["cpu_baseline"] = {"value": round(done / dtc, 3), "unit": "pairs/s", "cores": 1, "kind": "port",
-                               "sample": "%d stereo pairs of the same set, two extractions + stereo matches, oracle single thread, %.1f s" % (done, dtc)}
+    if c.world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(None, nfeat, warm=4, timed=60, stereo=(L, R, mb, mbf))
         out["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)
     print(json.dumps(out), flush=True)
 
 
+# ------------------------------------------------------------------------------------------------------------------------------
+# stream / rig workloads
+# ------------------------------------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames", type=int, default=256, help="frames per step and per GPU (resident in HBM)")
+    ap.add_argument("--frames", type=int, default=256, help="frames per step and per GPU, resident in HBM (rig workload: per step over ALL GPUs, 8 cameras x frames/8)")
     ap.add_argument("--workload", default="vga_stream_640x480_8lvl_1000feat_extract+match", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive pass (host frames in, host records out)")
     ap.add_argument("--no-match", action="store_true", help="extract only")
     ap.add_argument("--lanes", type=int, default=1, help="chunks in flight (each on its own HIP stream and handles)")
     ap.add_argument("--rows", action="store_true", help="measure the SURVEY 8(f) rows N1-N3 (device path vs the CPU restatement on the same inputs) "
@@ -176,49 +388,50 @@ def main():
     ap.add_argument("--bow", action="store_true", help="SearchByBoW proper: add ORBVocabulary::transform (synthetic k=10, L=6 tree) per frame and match "
                     "inside the FeatureVector groups instead of brute force (not the BASELINE configuration; reported as its own workload)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
 
     if args.rows:
         from tests import measure_next_rows
 
         return measure_next_rows.main()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args, sys.argv[1:])
+
+    c = setup(args)
+    torch, dist = c.torch, c.dist
+    rows, cols, nfeat = WORKLOADS[args.workload]
     if args.workload.startswith("kitti_stereo"):
-        if int(os.environ.get("WORLD_SIZE", "1")) > 1:
-            raise SystemExit("the stereo workload is single-GPU (pairs shard like frames; not wired into the multi-rank path)")
-        return run_stereo(args, *WORKLOADS[args.workload])
-
-    import torch
-    import torch.distributed as dist
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    local_rank %= max(torch.cuda.device_count(), 1)  # rehearsals with more ranks than GPUs share a device
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    # "nccl" IS RCCL on ROCm.  ORBX_DIST_BACKEND=gloo lets the multi-rank control flow be rehearsed on a one-GPU box
-    # (RCCL refuses two ranks on one device); the gather then stages through host memory.
-    backend = os.environ.get("ORBX_DIST_BACKEND", "nccl")
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        run_stereo(args, c, rows, cols, nfeat)
+        if c.world > 1:
+            dist.destroy_process_group()
+        return
 
     from orbslam3_cpp_fork_amd import shard, synth
-    from orbslam3_cpp_fork_amd.extractor import ORBextractor
+    from orbslam3_cpp_fork_amd.extractor import ORBextractor, pinned_array
     from orbslam3_cpp_fork_amd.matcher import ORBmatcher
 
-    rows, cols, nfeat = WORKLOADS[args.workload]
-    B = args.frames
-    # one camera per rank (frames shard by camera; consecutive frames of a camera stay on one GPU for matching)
-    frames_np = synth.make_stream(rows, cols, B, camera_idx=shard.camera_of_rank(rank, world))
+    rank, world, dev, local_rank, backend = c.rank, c.world, c.dev, c.local_rank, c.backend
+    rig = args.workload.startswith("rig_")
+    if rig:
+        # BASELINE config 5: 8 cameras dealt over the ranks; per step every camera delivers frames / 8 consecutive frames
+        if RIG_CAMERAS % world:
+            raise SystemExit("bench.py: the rig workload needs --gpus in {1, 2, 4, 8}")
+        cams = shard.cameras_of_rank(rank, world, RIG_CAMERAS)
+        per_cam = max(2, args.frames // RIG_CAMERAS)
+        frames_np = np.concatenate([synth.make_stream(rows, cols, per_cam, camera_idx=cam) for cam in cams])
+        B = len(frames_np)
+        idx = np.arange(B)
+        prev = np.where(idx % per_cam == 0, idx + per_cam - 1, idx - 1)  # predecessor inside the same camera (wraps around)
+        pairs = np.stack([prev, idx], 1).astype(np.int32)
+        total_frames_per_step = per_cam * RIG_CAMERAS
+    else:
+        # one camera per rank (frames shard by camera; consecutive frames of a camera stay on one GPU for matching)
+        B = args.frames
+        frames_np = synth.make_stream(rows, cols, B, camera_idx=shard.camera_of_rank(rank, world))
+        pairs = np.stack([(np.arange(B) - 1) % B, np.arange(B)], 1).astype(np.int32)  # frame f-1 (query) vs frame f (train)
+        total_frames_per_step = B * world
     d_imgs = torch.from_numpy(frames_np).to(dev)
-
-    cap = None
-    pairs = np.stack([(np.arange(B) - 1) % B, np.arange(B)], 1).astype(np.int32)  # frame f-1 (query) vs frame f (train)
     d_pairs = torch.from_numpy(pairs).to(dev)
 
     voc = None
@@ -298,23 +511,16 @@ def main():
     lanes = [Lane() for _ in range(max(1, args.lanes))]
     cap = lanes[0].cap
 
-    def fence():
-        for ln in lanes:
-            ln.drain()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     for i in range(args.warmup):
         lanes[i % len(lanes)].step()
-    fence()
+    fence(c, lanes)
     for ln in lanes:
         ln.ex.set_profiling(True)
     t0 = time.perf_counter()
     for i in range(args.steps):
         lanes[i % len(lanes)].step(timed=True)
-    fence()
-    dt = time.perf_counter() - t0
+    fence(c, lanes)
+    dt = max_over_ranks(c, time.perf_counter() - t0)
     stages = []
     for ln in lanes:
         try:
@@ -329,16 +535,77 @@ def main():
         stage["bow_transform"] = float(np.mean(bev))
     for ln in lanes:
         ln.ex.set_profiling(False)
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    d_cnt, d_nm = lanes[0].d_cnt, lanes[0].d_nm
+    cnt = lanes[0].d_cnt.cpu().numpy()
+    nm = lanes[0].d_nm.cpu().numpy()
+    value = total_frames_per_step * args.steps / dt
 
-    total_frames = B * args.steps * world
-    value = total_frames / dt
-    cnt = d_cnt.cpu().numpy()
-    nm = d_nm.cpu().numpy()
+    # ---- PCIe-inclusive pass: the same steps fed from pinned host memory through the streaming ABI ------------------------------
+    pcie = None
+    if not args.no_pcie and voc is None:
+        depth = 3
+        exh = ORBextractor(nfeat, 1.2, 8, 20, 7, device=local_rank)
+        exh.set_async_depth(depth)
+        mth = ORBmatcher(0.7, True, device=local_rank)
+        from orbslam3_cpp_fork_amd._lib import KP_DTYPE
+
+        # two distinct chunks alternate (the second one = the first flipped upside down: other bytes, same statistics), so no step
+        # re-reads the chunk the previous step left in the caches
+        h_imgs = [pinned_array((B, rows, cols), np.uint8) for _ in range(2)]
+        h_imgs[0][:] = frames_np
+        h_imgs[1][:] = frames_np[:, ::-1, :]
+        h_kps = [pinned_array((B, cap), KP_DTYPE) for _ in range(depth)]
+        h_desc = [pinned_array((B, cap, 32), np.uint8) for _ in range(depth)]
+        h_cnt = [pinned_array((B, 2), np.int32) for _ in range(depth)]
+        d_match = [torch.full((B, cap), -1, dtype=torch.int32, device=dev) for _ in range(depth)]
+        d_nm = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(depth)]
+        h_match = [torch.empty((B, cap), dtype=torch.int32).pin_memory() for _ in range(depth)]
+        h_nm = [torch.empty(B, dtype=torch.int32).pin_memory() for _ in range(depth)]
+        evs = [torch.cuda.Event() for _ in range(depth)]
+        inflight = []
+
+        def finish(item):
+            t, slot = item
+            exh.wait(t)          # keypoints / descriptors / counts of the chunk are in h_kps / h_desc / h_cnt[slot]
+            evs[slot].synchronize()  # matches of the chunk are in h_match / h_nm[slot]
+
+        def host_step(i):
+            slot = i % depth
+            if len(inflight) == depth:
+                finish(inflight.pop(0))
+            t = exh.extract_async(h_imgs[i % 2], h_kps[slot], h_desc[slot], h_cnt[slot], cap, (0, 1000))
+            dk, dd, dc, st = exh.async_device_buffers(t)
+            if not args.no_match:
+                mth.match_pairs_device(dd, dk, dc, cap, d_pairs, B, d_match[slot], d_nm[slot], stream=st)
+                with torch.cuda.stream(torch.cuda.ExternalStream(st, device=dev)):
+                    h_match[slot].copy_(d_match[slot], non_blocking=True)
+                    h_nm[slot].copy_(d_nm[slot], non_blocking=True)
+                    evs[slot].record()
+            inflight.append((t, slot))
+
+        def host_drain():
+            while inflight:
+                finish(inflight.pop(0))
+
+        for i in range(max(args.warmup, 2)):
+            host_step(i)
+        host_drain()
+        fence(c)
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            host_step(i)
+        host_drain()
+        fence(c)
+        dth = max_over_ranks(c, time.perf_counter() - t0)
+        in_b = B * rows * cols
+        out_b = B * cap * 60 + B * 8 + (0 if args.no_match else B * cap * 4 + B * 4)
+        pcie = {
+            "value": round(total_frames_per_step * args.steps / dth, 2), "unit": "frames/s", "ms_per_step": round(dth / args.steps * 1e3, 4),
+            "h2d_GBps_per_gpu": round(in_b * args.steps / dth / 1e9, 2), "d2h_GBps_per_gpu": round(out_b * args.steps / dth / 1e9, 2),
+            "pcie_limit_frames_per_s_per_gpu": round(PCIE_PEAK_GBS * 1e9 / (rows * cols), 1),
+            "what": "same steps from pinned host memory via orbx_extract_async / orbx_wait (depth 3): timed region = H2D of every frame + kernels + D2H of every "
+                    "fixed-capacity keypoint / descriptor / count record and of the match lists; two distinct chunks alternate",
+            "keypoints_per_frame": float(h_cnt[(args.steps - 1) % depth][:, 0].mean()),
+        }
 
     if rank == 0:
         ab = algorithmic_bytes(rows, cols, nfeat)
@@ -352,24 +619,25 @@ def main():
         # only the keypoint records (quadtree) or gather through L2 (orientation/BRIEF): price those by the output term.
         per_frame = ab.get(dom, ab["output"])
         achieved = per_frame * B / (stage[dom] * 1e-3) / 1e9
-        # HBM traffic of that kernel from the committed PMC passes of the same command (FETCH_SIZE x gfx950 correction +
-        # WRITE_SIZE, collected by tools/collect_profiles.sh; bench.py itself cannot read hardware counters)
-        traffic = None
-        try:
-            summ = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
-            if summ.get("bench", {}).get("config", {}).get("frames_per_step_per_gpu") == B and cols == summ["bench"]["config"]["cols"]:
-                names = kernels[dom].replace("||", "+").split("+")
-                traffic = int(sum(summ["kernels"][n]["hbm_traffic_MB_per_launch"] for n in names) * 1e6)
-        except Exception:
-            traffic = None
-        # share of SIMD issue slots the dominant kernel spends on VALU instructions, from the committed SQ-counter pass of the same
-        # command (tools/sq_counters.sh + tools/sq_summary.py): the integer issue rate, not HBM, is this pipeline's ceiling
-        valu_frac = None
-        try:
-            sq = json.load(open(os.path.join(ROOT, "profiles", "r01_sq_summary.json")))
-            valu_frac = sq[kernels[dom].split("+")[0]]["valu_issue_frac"]
-        except Exception:
-            valu_frac = None
+        prof = profile_summaries()
+        traffic, traffic_src, valu = None, None, None
+        first = kernels[dom].split("+")[0]
+        if prof["pmc"]:
+            name, summ = prof["pmc"]
+            try:
+                if summ["bench"]["config"]["frames_per_step_per_gpu"] == B and cols == summ["bench"]["config"]["cols"]:
+                    traffic = int(sum(summ["kernels"][n]["hbm_traffic_MB_per_launch"] for n in kernels[dom].split("+")) * 1e6)
+                    traffic_src = "profiles/" + name
+            except Exception:
+                traffic = None
+        if prof["valu"]:
+            name, summ = prof["valu"]
+            try:
+                k = summ["kernels"][first]
+                valu = {"bound": "valu", "kernel": first, "achieved": k["valu_ginst_per_s"], "peak": summ["calibration"]["peak_ginst_per_s"], "unit": "G wave-instr/s",
+                        "frac": k["valu_frac"], "source": "profiles/" + name}
+            except Exception:
+                valu = None
         out = {
             "metric": "frames/s ORB extract+match (640x480, 8 lvl, 1000 feat)" if cols == 640 else "frames/s ORB extract+match",
             "value": round(value, 2),
@@ -379,7 +647,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if rig else "weak",
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic",
@@ -391,7 +659,8 @@ def main():
                 "cols": cols,
                 "nfeatures": nfeat,
                 "nlevels": 8,
-                "parallelism": "frames sharded by camera, %d rank(s)%s" % (world, ", RCCL gather of keypoints+descriptors to rank 0" if world > 1 else ""),
+                "parallelism": ("8 cameras dealt over %d rank(s) (%d per GPU)" % (world, RIG_CAMERAS // world) if rig else "frames sharded by camera, %d rank(s)" % world)
+                               + (", RCCL gather of keypoints+descriptors to rank 0" if world > 1 else ""),
                 "keypoints_per_frame": float(cnt[:, 0].mean()),
                 "matches_per_frame": float(nm.mean()) if not args.no_match else None,
             },
@@ -403,9 +672,10 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 6),
                 "traffic": traffic,
+                "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": per_frame * B,
                 "avg_launch_ms": round(stage[dom], 5),
-                "valu_issue_frac": valu_frac,
+                "valu": valu,
             },
             "stage_ms": {k: round(v, 5) for k, v in stage.items()},
             "pipeline_hbm": {
@@ -413,6 +683,7 @@ def main():
                 "achieved_GBps": round(ab["total"] * value / world / 1e9, 3),
                 "frac_of_peak": round(ab["total"] * value / world / 1e9 / HBM_PEAK_GBS, 6),
             },
+            "pcie_inclusive": pcie,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(frames_np, nfeat)

@@ -28,6 +28,22 @@ def build(force=False):
 _lib = None
 
 
+def select_native():
+    """Switch to a -march=native build of the same source, compiled on THIS host (bench.py's cpu_baseline leg).
+    Must be called before the library is first used; returns False (and keeps the portable build) if that is no longer possible or
+    the compile fails."""
+    global _SO
+    if _lib is not None:
+        return False
+    nat = os.path.join(_HERE, "_build", "liborb_oracle_native.so")
+    try:
+        subprocess.check_call(["make", "-C", _HERE, "-B", "native"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    except Exception:
+        return False
+    _SO = nat
+    return True
+
+
 def lib():
     global _lib
     if _lib is None:

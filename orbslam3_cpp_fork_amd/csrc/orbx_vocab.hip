@@ -441,7 +441,10 @@ void orbv_destroy(orbv_t* h) {
 
 int orbv_create(orbv_t** out, int k, int L, int n_nodes, const int* parent, const uint8_t* is_leaf, const uint8_t* desc32,
                 const double* weight, int device_id) {
-  if (!out || (n_nodes > 0 && (!parent || !is_leaf || !desc32 || !weight))) return -2;
+  if (!out || (n_nodes > 0 && (!parent || !is_leaf || !desc32 || !weight))) {
+    set_verr("orbv_create: null argument");
+    return -2;
+  }
   orbv_vocab* h  = nullptr;
   int         rc = vocab_new(&h, device_id);
   if (rc) return rc;

@@ -192,6 +192,16 @@ def test_bad_arguments_are_rejected_before_the_device():
     assert L.orbm_search_for_triangulation(None, None, None, None, None, 0, None, None, None, None, 0, 0, None, None, None, None, None, None, None, None, 8, 0, 0, 50, 1,
                                            None) == -2
     assert L.orbx_stereo_matches_batch_device(None, None, None, None, None, None, None, None, 1, 16, 0.5, 300.0, None, None, None, None) == -2
+    # the message of a failed orbm_* / orbv_* call is readable through its own getter AND through orbx_last_error() (one slot per thread)
+    assert L.orbm_search_in_windows(None, None, None, None, None, None, 0, None, None, None, None, 0, None, None, 8, 4.0, 2, 0.0, 1.0, 0.0, 1.0, 50, None) == -2
+    msg = L.orbm_last_error().decode()
+    assert "orbm_search_in_windows" in msg and L.orbx_last_error().decode() == msg
+    assert L.orbv_create(C.byref(h), 10, 6, 3, None, None, None, None, 0) == -2
+    assert L.orbv_last_error().decode() and L.orbx_last_error().decode() == L.orbv_last_error().decode()
+    # streaming entry points: argument errors before any device work
+    t = C.c_int(7)
+    assert L.orbx_extract_async(None, None, 1, 480, 640, 640, 640 * 480, 0, 0, None, None, None, 0, C.byref(t)) == -2 and t.value == -1
+    assert L.orbx_wait(None, 0) == -2 and L.orbx_set_async_depth(None, 2) == -2 and L.orbx_set_tap_contraction(None, 1) == -2
     # vocabulary text header checks happen on the host, before any allocation
     import tempfile
 

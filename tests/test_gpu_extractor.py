@@ -168,3 +168,67 @@ def test_unaligned_batch(oracle, repitch, monkeypatch):
         got = np.frombuffer(kps[f, :n].cpu().numpy().tobytes(), oracle.KP_DTYPE)
         assert got.tobytes() == k.tobytes() and (desc[f, :n].cpu().numpy() == dd).all()
     ex.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pinned", [True, False])
+def test_streaming_abi_chunks_in_flight(oracle, pinned):
+    """orbx_extract_async / orbx_wait: three chunks in flight, pinned (DMA direct) and pageable (staged) host memory, results equal
+    the oracle's frame by frame; the device-side records of a ticket equal what lands on the host."""
+    import torch
+
+    from orbslam3_cpp_fork_amd import synth
+    from orbslam3_cpp_fork_amd._lib import KP_DTYPE, OrbxError
+    from orbslam3_cpp_fork_amd.extractor import ORBextractor, pinned_array
+
+    h, w, nf, B, nchunks = 240, 320, 500, 3, 4
+    frames = synth.make_stream(h, w, B * nchunks, camera_idx=3)
+    ex = ORBextractor(nf, 1.2, 8, 20, 7)
+    oex = oracle.OracleExtractor(nf, 1.2, 8, 20, 7)
+    cap = ex.max_keypoints(h, w)
+    alloc = pinned_array if pinned else (lambda shape, dt: np.zeros(shape, dt))
+    imgs = [alloc((B, h, w), np.uint8) for _ in range(nchunks)]
+    for c in range(nchunks):
+        imgs[c][:] = frames[c * B: (c + 1) * B]
+    outs = [(alloc((B, cap), KP_DTYPE), alloc((B, cap, 32), np.uint8), alloc((B, 2), np.int32)) for _ in range(nchunks)]
+    ex.set_async_depth(3)
+    tickets = [ex.extract_async(imgs[c], *outs[c], cap, (0, 1000)) for c in range(3)]
+    with pytest.raises(OrbxError, match="all slots in flight"):
+        ex.extract_async(imgs[3], *outs[3], cap, (0, 1000))
+    # device-side view of ticket 1 (what a chained matcher would read)
+    dk, dd, dc, st = ex.async_device_buffers(tickets[1])
+    ex.wait(tickets[1])
+    dev_cnt = np.zeros((B, 2), np.int32)
+    torch.cuda.synchronize()
+    import ctypes as C
+
+    from orbslam3_cpp_fork_amd import _lib
+
+    hip = C.CDLL("libamdhip64.so")
+    assert hip.hipMemcpy(dev_cnt.ctypes.data_as(C.c_void_p), C.c_void_p(dc), dev_cnt.nbytes, 2) == 0
+    assert (dev_cnt == outs[1][2]).all()
+    ex.wait(tickets[0])
+    tickets.append(ex.extract_async(imgs[3], *outs[3], cap, (0, 1000)))  # slot of ticket 0 is free again
+    ex.wait(tickets[2])
+    ex.wait(tickets[3])
+    with pytest.raises(OrbxError, match="unknown ticket"):
+        ex.wait(tickets[3])
+    for c in range(nchunks):
+        k, d, cnt = outs[c]
+        for f in range(B):
+            rc0, k0, d0 = oex(frames[c * B + f], (0, 1000))
+            n = int(cnt[f, 0])
+            assert n == len(k0) and int(cnt[f, 1]) == rc0
+            assert (k[f, :n].view(np.uint32) == k0.view(np.uint32)).all() and (d[f, :n] == d0).all()
+
+
+@pytest.mark.gpu
+def test_min_threshold_above_ini_threshold(oracle, vga_frame):
+    """The reference never checks minThFAST <= iniThFAST (src/ORBextractor.cc:403-410): the retry then uses the HIGHER threshold."""
+    from orbslam3_cpp_fork_amd.extractor import ORBextractor
+
+    ex = ORBextractor(1000, 1.2, 8, 12, 30)
+    oex = oracle.OracleExtractor(1000, 1.2, 8, 12, 30)
+    rc, k, d = ex(vga_frame, None, (0, 0))
+    rc0, k0, d0 = oex(vga_frame, (0, 0))
+    assert rc == rc0 and len(k) == len(k0) and (k.view(np.uint32) == k0.view(np.uint32)).all() and (d == d0).all()
