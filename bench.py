@@ -542,6 +542,9 @@ def main():
     # ---- PCIe-inclusive pass: the same steps fed from pinned host memory through the streaming ABI ------------------------------
     pcie = None
     if not args.no_pcie and voc is None:
+        for ln in lanes:  # the resident pass is over: give its streams back (HIP streams share a few hardware queues)
+            ln.ex.close()
+            ln.mt.close()
         depth = 3
         exh = ORBextractor(nfeat, 1.2, 8, 20, 7, device=local_rank)
         exh.set_async_depth(depth)
@@ -558,15 +561,12 @@ def main():
         h_cnt = [pinned_array((B, 2), np.int32) for _ in range(depth)]
         d_match = [torch.full((B, cap), -1, dtype=torch.int32, device=dev) for _ in range(depth)]
         d_nm = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(depth)]
-        h_match = [torch.empty((B, cap), dtype=torch.int32).pin_memory() for _ in range(depth)]
-        h_nm = [torch.empty(B, dtype=torch.int32).pin_memory() for _ in range(depth)]
-        evs = [torch.cuda.Event() for _ in range(depth)]
+        h_match = [pinned_array((B, cap), np.int32) for _ in range(depth)]
+        h_nm = [pinned_array((B,), np.int32) for _ in range(depth)]
         inflight = []
 
         def finish(item):
-            t, slot = item
-            exh.wait(t)          # keypoints / descriptors / counts of the chunk are in h_kps / h_desc / h_cnt[slot]
-            evs[slot].synchronize()  # matches of the chunk are in h_match / h_nm[slot]
+            exh.wait(item)  # keypoints / descriptors / counts AND the chained match lists of the chunk are on the host
 
         def host_step(i):
             slot = i % depth
@@ -576,11 +576,9 @@ def main():
             dk, dd, dc, st = exh.async_device_buffers(t)
             if not args.no_match:
                 mth.match_pairs_device(dd, dk, dc, cap, d_pairs, B, d_match[slot], d_nm[slot], stream=st)
-                with torch.cuda.stream(torch.cuda.ExternalStream(st, device=dev)):
-                    h_match[slot].copy_(d_match[slot], non_blocking=True)
-                    h_nm[slot].copy_(d_nm[slot], non_blocking=True)
-                    evs[slot].record()
-            inflight.append((t, slot))
+                exh.async_download(t, h_match[slot], d_match[slot])
+                exh.async_download(t, h_nm[slot], d_nm[slot])
+            inflight.append(t)
 
         def host_drain():
             while inflight:
@@ -605,7 +603,11 @@ def main():
             "what": "same steps from pinned host memory via orbx_extract_async / orbx_wait (depth 3): timed region = H2D of every frame + kernels + D2H of every "
                     "fixed-capacity keypoint / descriptor / count record and of the match lists; two distinct chunks alternate",
             "keypoints_per_frame": float(h_cnt[(args.steps - 1) % depth][:, 0].mean()),
+            "matches_per_frame": None if args.no_match else float(h_nm[(args.steps - 1) % depth].mean()),
         }
+        exh.close()
+        mth.close()
+        del h_imgs, h_kps, h_desc, h_cnt, h_match, h_nm
 
     if rank == 0:
         ab = algorithmic_bytes(rows, cols, nfeat)

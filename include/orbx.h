@@ -97,6 +97,9 @@ int orbx_extract_batch_device(orbx_t* h, const uint8_t* d_imgs, int nframes, int
  *   orbx_async_device_buffers  the device-side records of a ticket in flight and the stream its kernels were enqueued on, so
  *                       that the caller can chain device work (orbm_match_pairs_device, orbv_transform_batch_device ...) behind
  *                       the extraction without another upload.  Valid until the slot is reused (depth submissions later).
+ *   orbx_async_download enqueues one more device -> host copy for a ticket in flight, ordered behind everything enqueued so far
+ *                       on the ticket's stream (the results of the chained work); host_dst must be pinned.  orbx_wait(ticket)
+ *                       then covers it as well.
  * Returns 0, -1 (empty input), -2, -3 as above. */
 void* orbx_host_alloc(size_t bytes); /* pinned host memory (hipHostMalloc); NULL on failure */
 void  orbx_host_free(void* p);
@@ -105,6 +108,7 @@ int   orbx_extract_async(orbx_t* h, const uint8_t* imgs, int nframes, int rows, 
                          int lap0, int lap1, orbx_keypoint_t* kps, uint8_t* desc, int* counts, int cap, int* ticket);
 int   orbx_async_device_buffers(orbx_t* h, int ticket, const orbx_keypoint_t** d_kps, const uint8_t** d_desc, const int** d_counts,
                                 void** stream);
+int   orbx_async_download(orbx_t* h, int ticket, void* host_dst, const void* device_src, size_t bytes);
 int   orbx_wait(orbx_t* h, int ticket);
 
 /* mvImagePyramid[level] (public member, include/ORBextractor.h:87; read by Frame::ComputeStereoMatches,

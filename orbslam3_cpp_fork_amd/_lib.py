@@ -39,6 +39,7 @@ SIGNATURES = {
     "orbx_set_async_depth": (_i, [_vp, _i]),
     "orbx_extract_async": (_i, [_vp, _vp, _i, _i, _i, _sz, _sz, _i, _i, _vp, _vp, _vp, _i, _ip]),
     "orbx_async_device_buffers": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
+    "orbx_async_download": (_i, [_vp, _i, _vp, _vp, _sz]),
     "orbx_wait": (_i, [_vp, _i]),
     "orbx_undistort_keypoints": (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp]),
     "orbx_undistort_keypoints_device": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _vp]),

@@ -588,10 +588,11 @@ int orbx_create(orbx_t** out, int nfeatures, float scale_factor, int nlevels, in
     delete h;
     return -3;
   }
-  if (hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) != hipSuccess ||
-      hipEventCreateWithFlags(&h->evFork, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&h->evJoin, hipEventDisableTiming) != hipSuccess || hipEventCreate(&h->evBlur0) != hipSuccess ||
-      hipEventCreate(&h->evBlur1) != hipSuccess) {
+  // The side stream exists only when asked for: HIP streams share a handful of hardware queues, and every idle stream of a handle
+  // makes it likelier that two streams which should overlap (kernels / copy-out) land on the same queue.
+  if (h->overlapBlur && (hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) != hipSuccess ||
+                         hipEventCreateWithFlags(&h->evFork, hipEventDisableTiming) != hipSuccess ||
+                         hipEventCreateWithFlags(&h->evJoin, hipEventDisableTiming) != hipSuccess)) {
     g_err = "hipStreamCreate/hipEventCreate (side stream) failed";
     delete h;
     return -3;
@@ -839,6 +840,19 @@ static int ensure_pinned(uint8_t** p, size_t* capBytes, size_t need) {
   return 0;
 }
 
+// Device -> pinned host on `s`: the low-occupancy copy kernel when both ends are 16-byte aligned, else the runtime's copy.
+static int copy_out(hipStream_t s, void* host_dst, const void* dev_src, size_t bytes) {
+  if (bytes == 0) return 0;
+  if (((reinterpret_cast<uintptr_t>(host_dst) | reinterpret_cast<uintptr_t>(dev_src)) & 15) == 0 && (bytes & 3) == 0 && !getenv("ORBX_RUNTIME_D2H")) {
+    const long long n16 = (long long)(bytes >> 4);
+    hipLaunchKernelGGL(orbx::k_copy_out, dim3(orbx::kCopyOutBlocks), dim3(256), 0, s, (const orbx::u32x4*)dev_src, (orbx::u32x4*)host_dst, n16, (int)((bytes & 15) >> 2));
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
+  HIP_TRY(hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, s));
+  return 0;
+}
+
 int orbx_extract_async(orbx_t* h, const uint8_t* imgs, int nframes, int rows, int cols, size_t step_bytes, size_t frame_stride_bytes, int lap0,
                        int lap1, orbx_keypoint_t* kps, uint8_t* desc, int* counts, int cap, int* ticket) {
   if (ticket) *ticket = -1;
@@ -896,13 +910,13 @@ int orbx_extract_async(orbx_t* h, const uint8_t* imgs, int nframes, int rows, in
   if (sl.stagedOut) {
     rc = ensure_pinned(&sl.hOut, &sl.hOutCap, kpBytes + dBytes + cBytes);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(sl.hOut, sl.dKps.p, kpBytes, hipMemcpyDeviceToHost, h->sOut));
-    HIP_TRY(hipMemcpyAsync(sl.hOut + kpBytes, sl.dDesc.p, dBytes, hipMemcpyDeviceToHost, h->sOut));
-    HIP_TRY(hipMemcpyAsync(sl.hOut + kpBytes + dBytes, sl.dCounts.p, cBytes, hipMemcpyDeviceToHost, h->sOut));
+    if ((rc = copy_out(h->sOut, sl.hOut, sl.dKps.p, kpBytes)) || (rc = copy_out(h->sOut, sl.hOut + kpBytes, sl.dDesc.p, dBytes)) ||
+        (rc = copy_out(h->sOut, sl.hOut + kpBytes + dBytes, sl.dCounts.p, cBytes)))
+      return rc;
   } else {
-    HIP_TRY(hipMemcpyAsync(kps, sl.dKps.p, kpBytes, hipMemcpyDeviceToHost, h->sOut));
-    HIP_TRY(hipMemcpyAsync(desc, sl.dDesc.p, dBytes, hipMemcpyDeviceToHost, h->sOut));
-    HIP_TRY(hipMemcpyAsync(counts, sl.dCounts.p, cBytes, hipMemcpyDeviceToHost, h->sOut));
+    if ((rc = copy_out(h->sOut, kps, sl.dKps.p, kpBytes)) || (rc = copy_out(h->sOut, desc, sl.dDesc.p, dBytes)) ||
+        (rc = copy_out(h->sOut, counts, sl.dCounts.p, cBytes)))
+      return rc;
   }
   HIP_TRY(hipEventRecord(sl.evDone, h->sOut));
   sl.ticket = t, sl.nframes = nframes, sl.cap = cap, sl.uKps = kps, sl.uDesc = desc, sl.uCounts = counts;
@@ -927,6 +941,27 @@ int orbx_async_device_buffers(orbx_t* h, int ticket, const orbx_keypoint_t** d_k
   if (d_desc) *d_desc = sl->dDesc.p;
   if (d_counts) *d_counts = sl->dCounts.p;
   if (stream) *stream = (void*)h->stream;
+  return 0;
+}
+
+int orbx_async_download(orbx_t* h, int ticket, void* host_dst, const void* device_src, size_t bytes) {
+  orbx_extractor::AsyncSlot* sl = find_slot(h, ticket);
+  if (!sl || !host_dst || !device_src) {
+    g_err = "orbx_async_download: unknown ticket or null pointer";
+    return -2;
+  }
+  if (bytes == 0) return 0;
+  if (!is_pinned(host_dst)) {
+    g_err = "orbx_async_download: the destination must be pinned host memory (orbx_host_alloc)";
+    return -2;
+  }
+  HIP_TRY(hipSetDevice(h->device));
+  // behind everything enqueued so far on the ticket's kernel stream, on the copy-out stream; orbx_wait(ticket) then covers it too
+  HIP_TRY(hipEventRecord(sl->evCompute, h->stream));
+  HIP_TRY(hipStreamWaitEvent(h->sOut, sl->evCompute, 0));
+  int rc = copy_out(h->sOut, host_dst, device_src, bytes);
+  if (rc) return rc;
+  HIP_TRY(hipEventRecord(sl->evDone, h->sOut));
   return 0;
 }
 

@@ -1385,6 +1385,27 @@ __global__ __launch_bounds__(256) void k_undistort(const KpRec* __restrict__ kps
 }
 
 // ------------------------------------------------------------------------------------------------
+// Copy-out of result records to pinned host memory (orbx_extract_async / orbx_async_download).  The runtime's own device -> host
+// copy behind a kernel dependency is a full-grid shader blit that takes the whole GPU for the duration of a PCIe-bound transfer;
+// this one keeps a handful of workgroups busy (32 x 256 lanes x 4 x 16 B = 512 KB in flight covers the link's latency x
+// bandwidth product) and runs beside the next chunk's kernels from its own stream.  n16 = number of 16-byte words; tail4 dwords follow.
+// ------------------------------------------------------------------------------------------------
+constexpr int kCopyOutBlocks = 32;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_copy_out(const u32x4* __restrict__ src, u32x4* __restrict__ dst, long long n16, int tail4) {
+  const long long stride = (long long)gridDim.x * 256;
+  long long       i      = (long long)blockIdx.x * 256 + threadIdx.x;
+  for (; i + 3 * stride < n16; i += 4 * stride) {
+    const u32x4 a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + stride);
+    const u32x4 c = __builtin_nontemporal_load(src + i + 2 * stride), d = __builtin_nontemporal_load(src + i + 3 * stride);
+    dst[i] = a, dst[i + stride] = b, dst[i + 2 * stride] = c, dst[i + 3 * stride] = d;
+  }
+  for (; i < n16; i += stride) dst[i] = __builtin_nontemporal_load(src + i);
+  if (blockIdx.x == 0 && (int)threadIdx.x < tail4)
+    reinterpret_cast<uint32_t*>(dst + n16)[threadIdx.x] = reinterpret_cast<const uint32_t*>(src + n16)[threadIdx.x];
+}
+
+// ------------------------------------------------------------------------------------------------
 // PMC calibration: stream `n` bytes with W bytes per lane per load (W = 1, 4, 16) and fold them into one word,
 // so that rocprofv3's FETCH_SIZE can be compared with a known byte count for each access width this library
 // uses (MI355X_MICROARCH.md, HBM: the counter is only calibrated for 16 B/lane streams).

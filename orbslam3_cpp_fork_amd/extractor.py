@@ -124,6 +124,11 @@ class ORBextractor:
         check(_lib.lib().orbx_async_device_buffers(self._h, ticket, C.byref(a), C.byref(b), C.byref(c), C.byref(s)), "orbx_async_device_buffers")
         return a.value, b.value, c.value, s.value
 
+    def async_download(self, ticket, host_dst, device_src, nbytes=None):
+        """One more D2H copy for a ticket in flight, behind what has been chained on its stream so far (host_dst: pinned_array)."""
+        n = host_dst.nbytes if nbytes is None else nbytes
+        check(_lib.lib().orbx_async_download(self._h, ticket, ptr(host_dst), ptr(device_src), n), "orbx_async_download")
+
     def wait(self, ticket):
         check(_lib.lib().orbx_wait(self._h, ticket), "orbx_wait")
 
@@ -188,6 +193,10 @@ def pinned_array(shape, dtype):
             self.p = p
 
         def __del__(self):
+            import sys
+
+            if sys is None or sys.is_finalizing():  # at interpreter shutdown the HIP runtime may already be gone: the OS reclaims the pages
+                return
             try:
                 _lib.lib().orbx_host_free(C.c_void_p(self.p))
             except Exception:
