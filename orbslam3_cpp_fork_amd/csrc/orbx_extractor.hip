@@ -125,7 +125,7 @@ struct orbx_extractor {
     orbx_keypoint_t*    uKps = nullptr;
     uint8_t*            uDesc = nullptr;
     int*                uCounts = nullptr;
-    bool                stagedOut = false;
+    bool                stagedOut = false, pendingOut = false;
   };
   static constexpr int kMaxAsyncDepth = 8;
   AsyncSlot          slots[kMaxAsyncDepth];
@@ -843,13 +843,45 @@ static int ensure_pinned(uint8_t** p, size_t* capBytes, size_t need) {
 // Device -> pinned host on `s`: the low-occupancy copy kernel when both ends are 16-byte aligned, else the runtime's copy.
 static int copy_out(hipStream_t s, void* host_dst, const void* dev_src, size_t bytes) {
   if (bytes == 0) return 0;
+  static const int dbgMode = getenv("ORBX_DBG_COPYOUT") ? atoi(getenv("ORBX_DBG_COPYOUT")) : 0;  // diagnosis only: 2 = skip, 3 = copy to device scratch
+  if (dbgMode == 2) return 0;
+  if (dbgMode == 3) {
+    static void* scratch = nullptr;
+    if (!scratch) HIP_TRY(hipMalloc(&scratch, 64 << 20));
+    host_dst = scratch;
+  }
   if (((reinterpret_cast<uintptr_t>(host_dst) | reinterpret_cast<uintptr_t>(dev_src)) & 15) == 0 && (bytes & 3) == 0 && !getenv("ORBX_RUNTIME_D2H")) {
     const long long n16 = (long long)(bytes >> 4);
-    hipLaunchKernelGGL(orbx::k_copy_out, dim3(orbx::kCopyOutBlocks), dim3(256), 0, s, (const orbx::u32x4*)dev_src, (orbx::u32x4*)host_dst, n16, (int)((bytes & 15) >> 2));
+    static const int blocks = getenv("ORBX_COPYOUT_BLOCKS") ? std::max(1, atoi(getenv("ORBX_COPYOUT_BLOCKS"))) : orbx::kCopyOutBlocks;
+    hipLaunchKernelGGL(orbx::k_copy_out, dim3(blocks), dim3(256), 0, s, (const orbx::u32x4*)dev_src, (orbx::u32x4*)host_dst, n16, (int)((bytes & 15) >> 2));
     HIP_TRY(hipGetLastError());
     return 0;
   }
   HIP_TRY(hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, s));
+  return 0;
+}
+
+// Enqueue the copy-out of a slot's records behind everything that is on the kernel stream NOW.
+static int flush_copy_out(orbx_t* h, orbx_extractor::AsyncSlot& sl) {
+  if (!sl.pendingOut) return 0;
+  sl.pendingOut = false;
+  const size_t nk = (size_t)sl.nframes * sl.cap;
+  const size_t kpBytes = nk * sizeof(orbx_keypoint_t), dBytes = nk * 32, cBytes = (size_t)sl.nframes * 2 * sizeof(int);
+  HIP_TRY(hipEventRecord(sl.evCompute, h->stream));
+  HIP_TRY(hipStreamWaitEvent(h->sOut, sl.evCompute, 0));
+  int rc;
+  if (sl.stagedOut) {
+    rc = ensure_pinned(&sl.hOut, &sl.hOutCap, kpBytes + dBytes + cBytes);
+    if (rc) return rc;
+    if ((rc = copy_out(h->sOut, sl.hOut, sl.dKps.p, kpBytes)) || (rc = copy_out(h->sOut, sl.hOut + kpBytes, sl.dDesc.p, dBytes)) ||
+        (rc = copy_out(h->sOut, sl.hOut + kpBytes + dBytes, sl.dCounts.p, cBytes)))
+      return rc;
+  } else {
+    if ((rc = copy_out(h->sOut, sl.uKps, sl.dKps.p, kpBytes)) || (rc = copy_out(h->sOut, sl.uDesc, sl.dDesc.p, dBytes)) ||
+        (rc = copy_out(h->sOut, sl.uCounts, sl.dCounts.p, cBytes)))
+      return rc;
+  }
+  HIP_TRY(hipEventRecord(sl.evDone, h->sOut));
   return 0;
 }
 
@@ -879,13 +911,30 @@ int orbx_extract_async(orbx_t* h, const uint8_t* imgs, int nframes, int rows, in
   }
   if (!h->sIn) {
     HIP_TRY(hipStreamCreateWithFlags(&h->sIn, hipStreamNonBlocking));
-    HIP_TRY(hipStreamCreateWithFlags(&h->sOut, hipStreamNonBlocking));
+    // The copy-out kernels must not share a hardware queue with the extraction kernels: HIP multiplexes its streams onto a few
+    // hardware queues (least-referenced first), and two streams on one queue execute in submission order -- measured, the copy-out
+    // then ran strictly between orientation and matching instead of beside them.  A stream created with a CU mask always owns a
+    // queue; the mask itself enables every CU (ORBX_COPYOUT_CUS = n restricts the copy-out to the first n CUs of the mask).
+    {
+      uint32_t   mask[8];
+      const int  ncu = getenv("ORBX_COPYOUT_CUS") ? atoi(getenv("ORBX_COPYOUT_CUS")) : 256;
+      for (int i = 0; i < 8; i++) {
+        const int lo = 32 * i, n = std::min(std::max(ncu - lo, 0), 32);
+        mask[i] = n >= 32 ? 0xffffffffu : ((1u << n) - 1u);
+      }
+      if (getenv("ORBX_COPYOUT_PLAIN_STREAM") || hipExtStreamCreateWithCUMask(&h->sOut, 8, mask) != hipSuccess) {
+        (void)hipGetLastError();
+        HIP_TRY(hipStreamCreateWithFlags(&h->sOut, hipStreamNonBlocking));
+      }
+    }
   }
   if (!sl.evIn) {
     HIP_TRY(hipEventCreateWithFlags(&sl.evIn, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&sl.evCompute, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&sl.evDone, hipEventDisableTiming));
   }
+  for (auto& other : h->slots)  // records of earlier tickets that nobody has asked for yet go out now
+    if (other.ticket >= 0 && (rc = flush_copy_out(h, other))) return rc;
   const size_t inBytes = frame_stride_bytes * (size_t)(nframes - 1) + step_bytes * (size_t)(rows - 1) + cols;
   const size_t nk = (size_t)nframes * cap;
   if (sl.dIn.ensure(inBytes + 256) || sl.dKps.ensure(nk) || sl.dDesc.ensure(nk * 32) || sl.dCounts.ensure((size_t)nframes * 2)) return -3;
@@ -903,22 +952,13 @@ int orbx_extract_async(orbx_t* h, const uint8_t* imgs, int nframes, int rows, in
   rc = h->runResized(sl.dIn.p, nframes, rows, cols, step_bytes, frame_stride_bytes, lap0, lap1, sl.dKps.p, sl.dDesc.p, sl.dCounts.p, cap, h->stream);
   if (rc) return rc;
   HIP_TRY(hipEventRecord(sl.evCompute, h->stream));
-  // download of the fixed-capacity records
-  HIP_TRY(hipStreamWaitEvent(h->sOut, sl.evCompute, 0));
-  const size_t kpBytes = nk * sizeof(orbx_keypoint_t), dBytes = nk * 32, cBytes = (size_t)nframes * 2 * sizeof(int);
+  // The download of the fixed-capacity records is enqueued LATER (flush_copy_out): at the first orbx_async_download / orbx_wait for
+  // this ticket or at the next submission.  Chained work (a matcher on the ticket's stream) is then already in the queue, the
+  // copy-out waits for it too and runs beside the NEXT chunk's pyramid / FAST launches -- thousands of small workgroups that share
+  // the machine gracefully -- instead of beside the chained kernels (measured: the brute-force match took twice as long with the
+  // copy-out next to it).
   sl.stagedOut = !(is_pinned(kps) && is_pinned(desc) && is_pinned(counts));
-  if (sl.stagedOut) {
-    rc = ensure_pinned(&sl.hOut, &sl.hOutCap, kpBytes + dBytes + cBytes);
-    if (rc) return rc;
-    if ((rc = copy_out(h->sOut, sl.hOut, sl.dKps.p, kpBytes)) || (rc = copy_out(h->sOut, sl.hOut + kpBytes, sl.dDesc.p, dBytes)) ||
-        (rc = copy_out(h->sOut, sl.hOut + kpBytes + dBytes, sl.dCounts.p, cBytes)))
-      return rc;
-  } else {
-    if ((rc = copy_out(h->sOut, kps, sl.dKps.p, kpBytes)) || (rc = copy_out(h->sOut, desc, sl.dDesc.p, dBytes)) ||
-        (rc = copy_out(h->sOut, counts, sl.dCounts.p, cBytes)))
-      return rc;
-  }
-  HIP_TRY(hipEventRecord(sl.evDone, h->sOut));
+  sl.pendingOut = true;
   sl.ticket = t, sl.nframes = nframes, sl.cap = cap, sl.uKps = kps, sl.uDesc = desc, sl.uCounts = counts;
   h->nextTicket = t + 1;
   *ticket = t;
@@ -957,9 +997,15 @@ int orbx_async_download(orbx_t* h, int ticket, void* host_dst, const void* devic
   }
   HIP_TRY(hipSetDevice(h->device));
   // behind everything enqueued so far on the ticket's kernel stream, on the copy-out stream; orbx_wait(ticket) then covers it too
-  HIP_TRY(hipEventRecord(sl->evCompute, h->stream));
-  HIP_TRY(hipStreamWaitEvent(h->sOut, sl->evCompute, 0));
-  int rc = copy_out(h->sOut, host_dst, device_src, bytes);
+  int rc = 0;
+  if (sl->pendingOut) {
+    rc = flush_copy_out(h, *sl);  // records its own event behind the chained work
+    if (rc) return rc;
+  } else {
+    HIP_TRY(hipEventRecord(sl->evCompute, h->stream));
+    HIP_TRY(hipStreamWaitEvent(h->sOut, sl->evCompute, 0));
+  }
+  rc = copy_out(h->sOut, host_dst, device_src, bytes);
   if (rc) return rc;
   HIP_TRY(hipEventRecord(sl->evDone, h->sOut));
   return 0;
@@ -972,6 +1018,8 @@ int orbx_wait(orbx_t* h, int ticket) {
     return -2;
   }
   HIP_TRY(hipSetDevice(h->device));
+  int rc = flush_copy_out(h, *sl);
+  if (rc) return rc;
   HIP_TRY(hipEventSynchronize(sl->evDone));
   if (sl->stagedOut) {
     const size_t nk = (size_t)sl->nframes * sl->cap, kpBytes = nk * sizeof(orbx_keypoint_t), dBytes = nk * 32;

@@ -1386,11 +1386,13 @@ __global__ __launch_bounds__(256) void k_undistort(const KpRec* __restrict__ kps
 
 // ------------------------------------------------------------------------------------------------
 // Copy-out of result records to pinned host memory (orbx_extract_async / orbx_async_download).  The runtime's own device -> host
-// copy behind a kernel dependency is a full-grid shader blit that takes the whole GPU for the duration of a PCIe-bound transfer;
-// this one keeps a handful of workgroups busy (32 x 256 lanes x 4 x 16 B = 512 KB in flight covers the link's latency x
-// bandwidth product) and runs beside the next chunk's kernels from its own stream.  n16 = number of 16-byte words; tail4 dwords follow.
+// copy is a full-grid shader blit (no SDMA for this direction here), and ANY kernel that stores to host memory faster than PCIe
+// drains it fills the memory-side write queues with host-bound lines: kernels running beside it then stall on their own HBM
+// writes (measured: a 66 us pyramid launch took 300 us next to an unthrottled copy).  So this copy keeps only about one
+// few KB in flight -- kCopyOutBlocks x 4 waves x 4 KB, every wave drains its stores (vmcnt(0)) before it issues
+// the next 4 KB -- and runs on a stream of its own beside the next chunk's kernels.  n16 = 16-byte words; tail4 dwords follow.
 // ------------------------------------------------------------------------------------------------
-constexpr int kCopyOutBlocks = 32;
+constexpr int kCopyOutBlocks = 2;  // measured at VGA: 1 -> 152 k, 2 -> 160 k, 3 -> 154 k, 4 -> 147 k, 8 -> 140 k frames/s PCIe-inclusive (no copy-out at all: 162 k)
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void k_copy_out(const u32x4* __restrict__ src, u32x4* __restrict__ dst, long long n16, int tail4) {
   const long long stride = (long long)gridDim.x * 256;
@@ -1399,6 +1401,7 @@ __global__ __launch_bounds__(256) void k_copy_out(const u32x4* __restrict__ src,
     const u32x4 a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + stride);
     const u32x4 c = __builtin_nontemporal_load(src + i + 2 * stride), d = __builtin_nontemporal_load(src + i + 3 * stride);
     dst[i] = a, dst[i + stride] = b, dst[i + 2 * stride] = c, dst[i + 3 * stride] = d;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // throttle: at most 4 KB per wave on its way to the host
   }
   for (; i < n16; i += stride) dst[i] = __builtin_nontemporal_load(src + i);
   if (blockIdx.x == 0 && (int)threadIdx.x < tail4)
