@@ -155,6 +155,11 @@ int orbx_debug_level_keypoints(orbx_t* h, int frame, int level, uint32_t* out, i
 int orbx_debug_octree_times(orbx_t* h, long long* out, int cap);
 /* PMC calibration: stream nbytes of scratch memory with `width` (1, 4 or 16) bytes per lane per load. */
 int orbx_debug_calib_read(orbx_t* h, long long nbytes, int width);
+/* VALU issue-rate calibration (csrc/orbx_calib.hip): independent chains of one instruction class with waves_per_simd (1 .. 8) waves
+ * resident per SIMD on every CU.  out = {nanoseconds of the launch, median shader cycles per wave, wave-instructions per wave};
+ * orbx_debug_valu_calib_name(op) names the instruction (NULL past the last one).  Tuning hook: tools/valu_calibrate.py. */
+int         orbx_debug_valu_calib(int op, int waves_per_simd, int iters, double out[3]);
+const char* orbx_debug_valu_calib_name(int op);
 /* Device run of DistributeOctTree alone on caller-supplied candidates (host arrays). */
 int orbx_debug_octree_device(orbx_t* h, const uint32_t* cand, int n, int W, int H, int N, uint32_t* out, int* out_count);
 

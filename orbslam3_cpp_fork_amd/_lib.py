@@ -54,6 +54,8 @@ SIGNATURES = {
     "orbx_debug_level_keypoints": (_i, [_vp, _i, _i, _vp, _i]),
     "orbx_debug_octree_times": (_i, [_vp, _vp, _i]),
     "orbx_debug_calib_read": (_i, [_vp, C.c_longlong, _i]),
+    "orbx_debug_valu_calib": (_i, [_i, _i, _i, _vp]),
+    "orbx_debug_valu_calib_name": (C.c_char_p, [_i]),
     "orbx_debug_octree_device": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _ip]),
     "orbm_create": (_i, [C.POINTER(_vp), _i]),
     "orbm_destroy": (None, [_vp]),

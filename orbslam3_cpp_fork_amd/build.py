@@ -9,9 +9,9 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "liborbx.so")
-HIP_SOURCES = ["orbx_extractor.hip", "orbx_matcher.hip", "orbx_vocab.hip"]
+HIP_SOURCES = ["orbx_extractor.hip", "orbx_matcher.hip", "orbx_vocab.hip", "orbx_calib.hip"]
 HOST_SOURCES = ["orbx_hostmodel.cpp"]
-HEADERS = ["orbx_kernels.h", "orbx_geom.h", "octree_core.h", "orb_sincosf_port.h", "orb_pattern.inc", "../../include/orbx.h"]
+HEADERS = ["orbx_kernels.h", "orbx_fast_tiles.h", "orbx_geom.h", "octree_core.h", "orb_sincosf_port.h", "orb_pattern.inc", "../../include/orbx.h"]
 # -ffp-contract=off: float expressions must evaluate as the reference writes them (no FMA fusion).
 # Division/sqrt stay correctly rounded (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt); no fast-math.
 HIPFLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]

@@ -159,6 +159,10 @@ struct orbx_extractor {
   DevBuf<orbx::KpRec>        dKpOut;
   int                        stagePitch = 0;
   int                        fastGrid   = 0;
+  DevBuf<orbx::FastTile>     dTiles;      // k_fast_tiles: tile table + XCD-aware launch order
+  DevBuf<int>                dTileOrder;
+  int                        tileGrid = 0;
+  orbx::FastLds2             fastLds2{};
 
   // optional cv::resize of the input before extraction (System::TrackMonocular etc., src/System.cc:472-478)
   int          preW = 0, preH = 0, preSrcW = 0, preSrcH = 0;
@@ -340,6 +344,123 @@ int orbx_extractor::makeGeometry(int rows, int cols) {
     if (dCellDesc.ensure(desc.size() + 2)) return -3;
     HIP_TRY(hipMemcpy(dCellDesc.p, desc.data(), desc.size() * sizeof(int4), hipMemcpyHostToDevice));
   }
+  // ---- k_fast_tiles: tiles = runs of horizontally adjacent valid cells of one cell row (orbx_fast_tiles.h)
+  {
+    auto magic = [](unsigned d) { return d <= 1 ? 0u : 0xffffffffu / d + 1u; };
+    const int              kTileBudget = getenv("ORBX_FAST_TILE_BYTES") ? atoi(getenv("ORBX_FAST_TILE_BYTES")) : 8192;  // LDS bytes of one pixel tile
+    std::vector<FastTile>  tiles;
+    struct RowRef {
+      int first, count, px;
+    };
+    std::vector<RowRef> rowsOfTiles;
+    int maxTileBytes = 0, maxCells = 1, maxW = 1;
+    for (int l = 0; l < nlevels; l++) {
+      const LevelGeom& L = g.lv[l];
+      int              lastTile = -1;  // tile that zeroes the counts of the skipped cells after it
+      for (int i = 0; i < L.nRows; i++) {
+        const int iniY = kMinBorder + i * L.hCell;
+        int       nv   = 0;  // valid cells of this row are a prefix 0 .. nv - 1
+        int       ih   = 0;
+        if (iniY < L.maxBY - 3) {
+          ih = std::min(iniY + L.hCell + 6, L.maxBY) - iniY - 6;
+          if (ih > 0)
+            for (int j = 0; j < L.nCols; j++) {
+              const int iniX = kMinBorder + j * L.wCell;
+              if (iniX >= L.maxBX - 6 || std::min(iniX + L.wCell + 6, L.maxBX) - iniX - 6 <= 0) break;
+              nv++;
+            }
+        }
+        const int rowCell0 = L.cellBase + i * L.nCols;
+        if (nv == 0) {  // the whole row is skipped by the reference: its counts are zeroed by the previous tile
+          if (lastTile < 0) {
+            g_err = "FAST grid: first cell row of a level is empty";
+            return -2;
+          }
+          tiles[lastTile].nzero += L.nCols;
+          continue;
+        }
+        const int th = ih + 6;
+        // cells per tile: LDS pitch x rows within the budget, pitch <= 256 bytes (64 staging lanes), <= 16 pre-test passes
+        int G = 1;
+        for (int c = 2; c <= nv; c++) {
+          const int pitch = 4 * ((3 + c * L.wCell + 6 + 3) / 4 + 2);
+          const int ng    = (c * L.wCell + 3 + 3) / 4 + 1;
+          if (pitch > 256 || pitch * th > kTileBudget || (ng * ih + kFastTileThreads - 1) / kFastTileThreads > kFastMaxPass) break;
+          G = c;
+        }
+        const int nt = (nv + G - 1) / G;
+        RowRef    rr{(int)tiles.size(), nt, 0};
+        for (int t = 0, j0 = 0; t < nt; t++) {
+          const int nc = nv / nt + (t < nv % nt ? 1 : 0);
+          FastTile  T{};
+          const int iniX0 = kMinBorder + j0 * L.wCell;             // first cell's sub-image origin
+          const int X0 = iniX0 + 3, xa = (X0 - 3) & ~3, ox = (X0 - 3) - xa;
+          const int jl = j0 + nc - 1, iniXl = kMinBorder + jl * L.wCell;
+          const int iwLast = std::min(iniXl + L.wCell + 6, L.maxBX) - iniXl - 6;
+          T.level = l, T.srcPitch = L.pitch;
+          T.srcOff = l == 0 ? (xa | (iniY << 16)) : (L.pyrOff + iniY * L.pitch + xa);
+          T.IW = (nc - 1) * L.wCell + iwLast, T.ih = ih, T.th = th, T.ox3 = ox + 3;
+          T.tw4 = (ox + T.IW + 6 + 3) / 4;
+          T.ldsPitch = 4 * (T.tw4 + 1);
+          if (((T.ldsPitch / 4) & 1) == 0) T.ldsPitch += 4;  // odd dword pitch: consecutive rows start on different banks
+          T.wCell = L.wCell, T.iwLast = iwLast, T.ncells = nc;
+          T.cell0 = rowCell0 + j0, T.slotBase = L.slotBase;
+          T.xoff = 3 + j0 * L.wCell, T.yoff = 3 + i * L.hCell;
+          T.g0 = T.ox3 >> 2;
+          T.NG = ((T.ox3 + T.IW - 1) >> 2) - T.g0 + 1;
+          T.nitems = T.NG * ih;
+          T.W = (L.wCell * ih + 31) / 32;
+          T.mNG = magic(T.NG), T.mWc = magic(L.wCell), T.mIw = magic(L.wCell), T.mIwLast = magic(iwLast);
+          T.nzero = (t == nt - 1) ? L.nCols - nv : 0;
+          if ((T.nitems + kFastTileThreads - 1) / kFastTileThreads > kFastMaxPass || T.tw4 > 64 || th > 127 || T.ldsPitch > 511) {
+            g_err = "FAST tile exceeds the kernel's limits (cell larger than expected)";
+            return -2;
+          }
+          maxTileBytes = std::max(maxTileBytes, T.ldsPitch * th), maxCells = std::max(maxCells, nc), maxW = std::max(maxW, T.W);
+          rr.px += T.IW * ih;
+          lastTile = (int)tiles.size();
+          tiles.push_back(T);
+          j0 += nc;
+        }
+        rowsOfTiles.push_back(rr);
+      }
+    }
+    // launch order: whole cell rows onto the least loaded XCD (by pixels), largest first; block b runs on XCD b % 8
+    std::stable_sort(rowsOfTiles.begin(), rowsOfTiles.end(), [](const RowRef& a, const RowRef& b) { return a.px > b.px; });
+    std::vector<std::vector<int>> perXcd(8);
+    long long                     load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (const RowRef& r : rowsOfTiles) {
+      int best = 0;
+      for (int x = 1; x < 8; x++)
+        if (load[x] < load[best]) best = x;
+      load[best] += r.px;
+      for (int t = 0; t < r.count; t++) perXcd[best].push_back(r.first + t);
+    }
+    size_t per = 0;
+    for (auto& v : perXcd) per = std::max(per, v.size());
+    std::vector<int> order(per * 8, -1);
+    for (int x = 0; x < 8; x++)
+      for (size_t k = 0; k < perXcd[x].size(); k++) order[k * 8 + x] = perXcd[x][k];
+    tileGrid = (int)order.size();
+    if (dTiles.ensure(tiles.size() + 1) || dTileOrder.ensure(order.size() + 1)) return -3;
+    HIP_TRY(hipMemcpy(dTiles.p, tiles.data(), tiles.size() * sizeof(FastTile), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dTileOrder.p, order.data(), order.size() * sizeof(int), hipMemcpyHostToDevice));
+    // LDS plan
+    const int region = alignUp(maxTileBytes + 32, 16);
+    FastLds2  fl{};
+    fl.scoreOff = alignUp(16 + region, 16);
+    fl.candOff  = fl.scoreOff + region;
+    fl.candCap  = getenv("ORBX_FAST_CAND_CAP") ? atoi(getenv("ORBX_FAST_CAND_CAP")) : 2048;
+    fl.mask1Off = alignUp(fl.candOff + 2 * fl.candCap, 16);
+    fl.mask2Off = fl.mask1Off + 4 * maxCells * maxW;
+    fl.cntOff   = fl.mask2Off + 4 * maxCells * maxW;
+    fl.total    = alignUp(fl.cntOff + 4 * (maxCells + 2), 16);
+    if (fl.total > 160 * 1024) {
+      g_err = "FAST tile LDS plan exceeds 160 KB";
+      return -2;
+    }
+    fastLds2 = fl;
+  }
   // upload tables
   if (dXtab.ensure(xt.size() + 1) || dYtab.ensure(yt.size() + 1) || dCellSlot.ensure(cellSlot.size() + 1)) return -3;
   HIP_TRY(hipMemcpy(dXtab.p, xt.data(), xt.size() * sizeof(int2), hipMemcpyHostToDevice));
@@ -490,6 +611,15 @@ int orbx_extractor::run(const uint8_t* d_imgs, int B, int rows, int cols, size_t
     HIP_TRY(hipEventRecord(evJoin, stream2));
   }
   if (prof) HIP_TRY(hipEventRecord(ev[1], s));
+  static const bool useCells = getenv("ORBX_FAST_CELLS") != nullptr;  // first-generation kernel (one workgroup per cell), kept for A/B runs
+  if (!useCells) {
+    const int t1 = std::min(std::max(iniTh, 0), 255), t2 = std::min(std::max(minTh, 0), 255);
+    static const int dbg = getenv("ORBX_DBG_SKIP_FAST") ? atoi(getenv("ORBX_DBG_SKIP_FAST")) : 0;  // ablation switch (tuning only)
+    if (al4)
+      hipLaunchKernelGGL((k_fast_tiles<true>), dim3(tileGrid, B), dim3(kFastTileThreads), fastLds2.total, s, b, g, dTiles.p, dTileOrder.p, t1, t2, fastLds2, dbg);
+    else
+      hipLaunchKernelGGL((k_fast_tiles<false>), dim3(tileGrid, B), dim3(kFastTileThreads), fastLds2.total, s, b, g, dTiles.p, dTileOrder.p, t1, t2, fastLds2, dbg);
+  } else
   {
     const int  per  = fastGrid / 8;  // order-table slots per XCD
     const dim3 grid(8 * ((per + kFastCellsPerBlock - 1) / kFastCellsPerBlock), B);
@@ -656,7 +786,7 @@ void orbx_destroy(orbx_t* h) {
     for (auto& slot : h->ev)
       for (auto& e : slot) hipEventDestroy(e);
   h->dPyr.release(), h->dBlur.release(), h->dStereoSad.release(), h->dRaw.release(), h->dPre.release(), h->dPreX.release(), h->dPreY.release(), h->dStage.release(), h->dDescOut.release(), h->dXtab.release(), h->dYtab.release();
-  h->dCellDesc.release(), h->dCellOrder.release(), h->dCellSlot.release(), h->dCellCount.release(), h->dNodeOf.release(), h->dCellOffs.release();
+  h->dTiles.release(), h->dTileOrder.release(), h->dCellDesc.release(), h->dCellOrder.release(), h->dCellSlot.release(), h->dCellCount.release(), h->dNodeOf.release(), h->dCellOffs.release();
   h->dD.release(), h->dDIndex.release(), h->dNCh.release(), h->dPushOff.release(), h->dMultiOff.release();
   h->dKeptRank.release(), h->dVA.release(), h->dVB.release(), h->dCandCount.release(), h->dLvlCount.release(), h->dOutIdx.release();
   h->dCounts.release(), h->dSlots.release(), h->dCand.release(), h->dLvlKp.release(), h->dNodesA.release(), h->dNodesB.release();

@@ -591,6 +591,10 @@ __global__ __launch_bounds__(kFastThreads, TS <= 52 ? 8 : 5) void k_fast_cells(B
   }
 }
 
+}  // namespace orbx
+#include "orbx_fast_tiles.h"
+namespace orbx {
+
 // ------------------------------------------------------------------------------------------------
 // DistributeOctTree: one workgroup per (frame, level).  First gathers the per-cell candidate slots into
 // the feed order of the reference (cells row-major, row-major inside a cell), then runs octree_core.h.

@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/sq_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --pmc $CNT --output-format csv -d $OUT -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/log.txt 2>&1
+timeout -k 10 300 rocprofv3 --pmc $CNT --output-format csv -d $OUT -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pcie > $OUT/log.txt 2>&1
 cd $R
 python3 - "$OUT" <<'PY'
 import csv, glob, collections, sys, re
