@@ -75,7 +75,10 @@ class ORBextractor {
   std::vector<float> inline GetInverseScaleSigmaSquares() { return mvInvLevelSigma2; }
 
   std::vector<orbx_cv::Mat> mvImagePyramid;            // host copies of the device pyramid of the last call
-  bool                      mbDownloadPyramid = true;  // monocular callers never read the pyramid: set false to skip the D2H copy
+  // Off by default: only Frame::ComputeStereoMatches reads mvImagePyramid (src/Frame.cc:950, 1039-1058), and with orbx_stereo_matches
+  // not even the stereo path needs host copies.  A caller that keeps the reference's host-side ComputeStereoMatches sets it to true
+  // (8 synchronous D2H copies per call).
+  bool                      mbDownloadPyramid = false;
   orbx_t*                   handle() { return h_; }
 
  protected:

@@ -204,6 +204,16 @@ class ORBmatcher {
 
   orbm_t* handle() { return h_; }
 
+  // The reference constructs its ORBmatcher on the stack at every call site (ORBmatcher matcher(0.9, true), src/Tracking.cc and
+  // others).  A device handle per such object would create a stream and buffers each time: the forwarding bodies use ONE handle
+  // per host thread instead and set the call site's parameters on it.
+  void SetParameters(float nnratio, bool checkOri) { mfNNratio = nnratio, mbCheckOrientation = checkOri; }
+  static ORBmatcher& ThreadInstance(float nnratio, bool checkOri, int device_id = 0) {
+    static thread_local ORBmatcher inst(nnratio, checkOri, device_id);
+    inst.SetParameters(nnratio, checkOri);
+    return inst;
+  }
+
  protected:
   float mfNNratio;
   bool  mbCheckOrientation;

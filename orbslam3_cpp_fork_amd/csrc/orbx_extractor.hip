@@ -601,8 +601,8 @@ int orbx_extractor::run(const uint8_t* d_imgs, int B, int rows, int cols, size_t
   };
   if (prof) HIP_TRY(hipEventRecord(ev[0], s));
   for (int l = 1; l < g.nlevels; l++) {
-    dim3 grid((g.lv[l].w + kRsTileW - 1) / kRsTileW, (g.lv[l].h + kRsTileH - 1) / kRsTileH, B), block(256, 1, 1);
-    hipLaunchKernelGGL(k_resize_level, grid, block, 0, s, b, g, l);
+    const int tx = (g.lv[l].w + kRsTileW - 1) / kRsTileW, ty = (g.lv[l].h + kRsTileH - 1) / kRsTileH;
+    hipLaunchKernelGGL(k_resize_level, dim3(8 * tx, ty, (B + 7) / 8), dim3(256), 0, s, b, g, l, B);
   }
   if (overlapBlur) {  // fork: the blur only needs the pyramid
     HIP_TRY(hipEventRecord(evFork, s));

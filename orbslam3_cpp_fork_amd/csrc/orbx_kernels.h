@@ -87,10 +87,10 @@ constexpr int kRsTileW = 128, kRsTileH = 16, kRsLdsW = 176, kRsLdsH = 25;  // on
 // rows when it enlarges); the pyramid only shrinks (scale > 1), where row sy + 1 always exists, and skips the test.
 template <bool CLAMP_ROWS>
 __device__ __forceinline__ void resize_tile(const uint8_t* __restrict__ S, int sp, int sw, int sh, uint8_t* __restrict__ D, int dp, int dw, int dh,
-                                            const int2* __restrict__ xtab, const int2* __restrict__ ytab) {
+                                            const int2* __restrict__ xtab, const int2* __restrict__ ytab, int tileX, int tileY) {
   __shared__ __align__(16) uint8_t src[kRsLdsH][kRsLdsW];
   const int        tid = threadIdx.x;
-  const int        dx0 = blockIdx.x * kRsTileW, dy0 = blockIdx.y * kRsTileH;
+  const int        dx0 = tileX * kRsTileW, dy0 = tileY * kRsTileH;
   const int        dxl = min(dx0 + kRsTileW, dw) - 1, dyl = min(dy0 + kRsTileH, dh) - 1;
   // source footprint of the tile (tables are monotone)
   const int sxa = xtab[dx0].x & ~3;
@@ -167,13 +167,20 @@ __device__ __forceinline__ void resize_tile(const uint8_t* __restrict__ S, int s
   }
 }
 
-__global__ __launch_bounds__(256) void k_resize_level(Bufs b, FrameGeom g, int level) {
+// Frame -> XCD affinity: workgroups are dealt round-robin over the 8 XCDs in linearised block order, and gridDim.x is a multiple of
+// 8, so blockIdx.x % 8 names the XCD.  grid = (8 x tiles across, tiles down, frames / 8): every tile of frame (x % 8) + 8 z runs on one
+// XCD and each source line of level l - 1 is pulled into ONE L2 -- with a plain (x, y, frame) grid neighbouring tiles, which share
+// source lines, went to different XCDs and the level was fetched almost twice (626 MB measured against 321 MB algorithmic per 256
+// VGA frames).  No index division anywhere.
+__global__ __launch_bounds__(256) void k_resize_level(Bufs b, FrameGeom g, int level, int nframes) {
+  const int f = (blockIdx.x & 7) + 8 * blockIdx.z;
+  if (f >= nframes) return;
   const LevelGeom& L  = g.lv[level];
   const LevelGeom& Ls = g.lv[level - 1];
   int              sp;
-  const uint8_t*   S = level_raw(b, g, level - 1, blockIdx.z, &sp);
-  resize_tile<false>(S, sp, Ls.w, Ls.h, b.pyr + (long long)blockIdx.z * g.pyrBytes + L.pyrOff, L.pitch, L.w, L.h, b.xtab + L.xtabOff,
-                     b.ytab + L.ytabOff);
+  const uint8_t*   S = level_raw(b, g, level - 1, f, &sp);
+  resize_tile<false>(S, sp, Ls.w, Ls.h, b.pyr + (long long)f * g.pyrBytes + L.pyrOff, L.pitch, L.w, L.h, b.xtab + L.xtabOff, b.ytab + L.ytabOff,
+                     blockIdx.x >> 3, blockIdx.y);
 }
 
 // cv::resize(im, im, cv::Size(newWidth, newHeight)) of System::TrackMonocular / TrackStereo / TrackRGBD (src/System.cc:472-478 and
@@ -181,7 +188,8 @@ __global__ __launch_bounds__(256) void k_resize_level(Bufs b, FrameGeom g, int l
 __global__ __launch_bounds__(256) void k_resize_input(const uint8_t* __restrict__ src, int sp, long long srcFrameStride, int sw, int sh,
                                                       uint8_t* __restrict__ dst, int dp, long long dstFrameStride, int dw, int dh,
                                                       const int2* __restrict__ xtab, const int2* __restrict__ ytab) {
-  resize_tile<true>(src + (long long)blockIdx.z * srcFrameStride, sp, sw, sh, dst + (long long)blockIdx.z * dstFrameStride, dp, dw, dh, xtab, ytab);
+  resize_tile<true>(src + (long long)blockIdx.z * srcFrameStride, sp, sw, sh, dst + (long long)blockIdx.z * dstFrameStride, dp, dw, dh, xtab, ytab,
+                    blockIdx.x, blockIdx.y);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -781,7 +789,7 @@ __device__ __forceinline__ int reflect101(int p, int n) {
 // horizontal Q8 sums of its 4 columns, keeps the last 7 of them in registers and emits one output row
 // (4 bytes, one store) per input row.  No LDS, no second pass; neighbouring lanes' overlapping loads hit L1.
 // Work items are dealt level by level, 256 per workgroup (LevelGeom::blurTileBase counts workgroups).
-constexpr int kBlurRows = 16;
+constexpr int kBlurRows = 16;  // rows per strip (32-row strips save the re-filtered halo rows but leave too few waves to hide the row loads: 0.19 -> 0.22 ms)
 constexpr int kBlurEdgeRows = 4;  // strip height of the edge items: few items, so short strips keep enough of them in flight
 
 // Three dwords covering columns x0-4 .. x0+7 of one row (reflect-101 at the image edges).

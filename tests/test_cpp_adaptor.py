@@ -99,3 +99,79 @@ def test_adaptor_matches_oracle(tmp_path, oracle):
         want += [int(i), int(m12[i])]
     assert row(5) == want
 
+
+
+# ---- the reference-side forwarding bodies of INTEGRATION.md section 3, compiled against mock Frame / KeyFrame / MapPoint classes ----
+def _build_bodies(tmp):
+    from orbslam3_cpp_fork_amd import build
+
+    so = build.build()
+    exe = os.path.join(tmp, "reference_matcher_bodies")
+    subprocess.check_call(
+        ["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), "-DORBX_NO_OPENCV",
+         os.path.join(ROOT, "tests", "cpp", "reference_matcher_bodies.cpp"), "-o", exe, "-L" + os.path.dirname(so), "-lorbx", "-Wl,-rpath," + os.path.dirname(so)]
+    )
+    return exe
+
+
+def test_reference_matcher_bodies_compile(tmp_path):
+    assert os.path.exists(_build_bodies(str(tmp_path)))
+
+
+@pytest.mark.gpu
+def test_reference_matcher_bodies_match_oracle(tmp_path, oracle):
+    """ORB_SLAM3::ORBmatcher::SearchByBoW / SearchForInitialization / SearchByProjection(Frame, Frame) with the bodies of INTEGRATION.md
+    (reference signatures src/ORBmatcher.cc:237, 666, 1684), driven through mock Frames, against the oracle's array-level restatements."""
+    from orbslam3_cpp_fork_amd import synth
+    from orbslam3_cpp_fork_amd.matcher import flatten_feature_vectors
+
+    exe = _build_bodies(str(tmp_path))
+    frames = synth.make_stream(480, 640, 2, camera_idx=5)
+    fa, fb, out = (str(tmp_path / n) for n in ("a.raw", "b.raw", "out.txt"))
+    frames[0].tofile(fa)
+    frames[1].tofile(fb)
+    voc = synth.make_vocabulary(10, 3, seed=23)
+    vpath = str(tmp_path / "voc.txt")
+    synth.write_vocabulary_text(vpath, 10, 3, *voc)
+    subprocess.check_call([exe, "480", "640", fa, fb, out, vpath], timeout=300)
+    lines = open(out).read().split("\n")
+    oex = oracle.OracleExtractor(1000, 1.2, 8, 20, 7)
+    _, kA, dA = oex(frames[0], (0, 1000))
+    _, kB, dB = oex(frames[1], (0, 1000))
+    nA, nB = len(kA), len(kB)
+    idx = np.arange(nA)
+    has_mp = idx % 3 != 2
+    bad = idx % 11 == 0
+    outlier = idx % 17 == 0
+    # (1) SearchByBoW(KeyFrame*, Frame&)
+    ov = oracle.OracleVocabulary(10, 3, *voc)
+    _, _, niA, noA, fiA, _, _ = ov.transform(dA, 1)
+    _, _, niB, noB, fiB, _, _ = ov.transform(dB, 1)
+    fvA = {int(niA[i]): fiA[noA[i]: noA[i + 1]].tolist() for i in range(len(niA))}
+    fvB = {int(niB[i]): fiB[noB[i]: noB[i + 1]].tolist() for i in range(len(niB))}
+    n, _, mt = oracle.match_groups(dA, dB, kA["angle"], kB["angle"], 50, 0.7, False, True, flatten_feature_vectors(fvA, fvB), q_valid=(has_mp & ~bad).astype(np.uint8))
+    assert [int(x) for x in lines[0].split()] == [nA, nB, n] and n > 30
+    assert [int(x) for x in lines[1: 1 + nB]] == mt.tolist()
+    p = 1 + nB
+    # (2) SearchForInitialization
+    prev = np.stack([kA["x"], kA["y"]], 1).astype(np.float32)
+    nw, m12, pm = oracle.match_window(dA, kA, dB, kB, prev, (0.0, 640.0, 0.0, 480.0), window=100, th=50, ratio=0.9, check_ori=True)
+    assert int(lines[p]) == nw and nw > 20
+    for i in range(nA):
+        v = lines[p + 1 + i].split()
+        assert int(v[0]) == int(m12[i]) and np.float32(float.fromhex(v[1])) == pm[i, 0] and np.float32(float.fromhex(v[2])) == pm[i, 1]
+    p += 1 + nA
+    # (3) SearchByProjection(CurrentFrame, LastFrame): projections and validity come from the (mock) loop head, the search from the oracle
+    npj = int(lines[p])
+    valid = np.zeros(nA, np.uint8)
+    uv = np.zeros((nA, 2), np.float32)
+    for i in range(nA):
+        v = lines[p + 1 + i].split()
+        valid[i], uv[i] = int(v[0]), (float.fromhex(v[1]), float.fromhex(v[2]))
+    assert (valid.astype(bool) <= (has_mp & ~outlier)).all() and valid.sum() > 300
+    dmp = np.where(valid[:, None].astype(bool), dA, 0).astype(np.uint8)
+    sf = oex.scale_tables()[0]
+    n3, col, loc = oracle.search_by_projection(dmp, uv, None, kA["octave"].astype(np.int32), kA["angle"], valid, dB, kB, None, np.zeros(nB, np.uint8), sf, 15.0, 0, 0.0,
+                                               (0.0, 640.0, 0.0, 480.0), 100, True)
+    assert npj == n3 and n3 > 100
+    assert [int(x) for x in lines[p + 1 + nA: p + 1 + nA + nB]] == loc.tolist()

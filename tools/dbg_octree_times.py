@@ -3,7 +3,7 @@ os.environ["ORBX_DBG_OCT"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from orbslam3_cpp_fork_amd import synth, _lib
 from orbslam3_cpp_fork_amd.extractor import ORBextractor
-B, rows, cols = 64, 480, 640
+B, rows, cols = (int(sys.argv[1]) if len(sys.argv) > 1 else 64), 480, 640
 fr = synth.make_stream(rows, cols, B)
 ts = torch.cuda.Stream(); torch.cuda.set_stream(ts)
 d = torch.from_numpy(fr).cuda()
