@@ -382,7 +382,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive pass (host frames in, host records out)")
     ap.add_argument("--no-match", action="store_true", help="extract only")
-    ap.add_argument("--lanes", type=int, default=1, help="chunks in flight (each on its own HIP stream and handles)")
+    ap.add_argument("--lanes", type=int, default=3, help="chunks in flight, each with its own handles, buffers and a HIP stream that owns a hardware queue: "
+                    "the latency-bound kernels of one chunk (quadtree, claim resolution) run beside the VALU-bound ones of the others; 1 = strictly serial")
     ap.add_argument("--rows", action="store_true", help="measure the SURVEY 8(f) rows N1-N3 (device path vs the CPU restatement on the same inputs) "
                     "instead of the headline workload: one JSON line per row (tests/measure_next_rows.py)")
     ap.add_argument("--bow", action="store_true", help="SearchByBoW proper: add ORBVocabulary::transform (synthetic k=10, L=6 tree) per frame and match "
@@ -454,9 +455,13 @@ def main():
             self.d_cnt = torch.zeros((B, 2), dtype=torch.int32, device=dev)
             self.d_match = torch.full((B, self.cap), -1, dtype=torch.int32, device=dev)
             self.d_nm = torch.zeros(B, dtype=torch.int32, device=dev)
-            self.tstream = torch.cuda.Stream(device=dev)  # explicit, non-default: NULL would select the handle's private stream
-            self.stream = self.tstream.cuda_stream
+            # a stream with a hardware queue of its own (orbx_stream_create): torch's pooled streams share a few queues, and two chunks
+            # on one queue would run strictly one after the other
+            from orbslam3_cpp_fork_amd import _lib as _L
+
+            self.stream = _L.lib().orbx_stream_create(local_rank)
             assert self.stream
+            self.tstream = torch.cuda.ExternalStream(self.stream, device=dev)
             self.gather = shard.RecordGather(B, self.cap, dev, world, rank, host_staged=(backend != "nccl")) if world > 1 else None
             self.pending = None
             self.match_ev = []
@@ -502,6 +507,16 @@ def main():
                         self.pending.wait()
                     self.pending = self.gather(self.d_kps, self.d_desc, self.d_cnt, async_op=True)
 
+        def close(self):
+            from orbslam3_cpp_fork_amd import _lib as _L
+
+            torch.cuda.synchronize()
+            self.ex.close()
+            self.mt.close()
+            if self.stream:
+                _L.lib().orbx_stream_destroy(self.stream)
+                self.stream = None
+
         def drain(self):
             if self.pending is not None:
                 with torch.cuda.stream(self.tstream):
@@ -535,6 +550,18 @@ def main():
         stage["bow_transform"] = float(np.mean(bev))
     for ln in lanes:
         ln.ex.set_profiling(False)
+    # the same stages with ONE chunk in flight (nothing running beside them): what a kernel costs on its own
+    stage_serial = None
+    if len(lanes) > 1:
+        ln = lanes[0]
+        ln.ex.set_profiling(True)
+        ln.match_ev = []
+        for _ in range(4):
+            ln.step(timed=True)
+            fence(c, lanes)
+        stage_serial = ln.ex.stage_ms()
+        stage_serial["match"] = float(np.mean([a.elapsed_time(b) for a, b in ln.match_ev])) if ln.match_ev else 0.0
+        ln.ex.set_profiling(False)
     cnt = lanes[0].d_cnt.cpu().numpy()
     nm = lanes[0].d_nm.cpu().numpy()
     value = total_frames_per_step * args.steps / dt
@@ -542,9 +569,8 @@ def main():
     # ---- PCIe-inclusive pass: the same steps fed from pinned host memory through the streaming ABI ------------------------------
     pcie = None
     if not args.no_pcie and voc is None:
-        for ln in lanes:  # the resident pass is over: give its streams back (HIP streams share a few hardware queues)
-            ln.ex.close()
-            ln.mt.close()
+        for ln in lanes:  # the resident pass is over: give its handles and queues back
+            ln.close()
         depth = 3
         exh = ORBextractor(nfeat, 1.2, 8, 20, 7, device=local_rank)
         exh.set_async_depth(depth)
@@ -657,6 +683,8 @@ def main():
                 "workload": args.workload + ("" if not args.no_match else " [extract only]") + (" [+ BoW transform, SearchByBoW over FeatureVector groups]" if voc is not None else ""),
                 "frames_per_step_per_gpu": B,
                 "chunks_in_flight": len(lanes),
+                "stage_ms_note": "stage_ms / roofline: HIP events on each chunk's own stream inside the timed region, i.e. WITH the other chunks' kernels running beside them; "
+                                 "stage_ms_one_chunk_in_flight: the same stages measured right after it with nothing beside them",
                 "rows": rows,
                 "cols": cols,
                 "nfeatures": nfeat,
@@ -678,8 +706,15 @@ def main():
                 "algorithmic_bytes_per_launch": per_frame * B,
                 "avg_launch_ms": round(stage[dom], 5),
                 "valu": valu,
+                # with several chunks in flight a launch shares the machine with the other chunks' kernels for its whole duration;
+                # the same kernel with the machine to itself (measured right after the timed region):
+                "one_chunk_in_flight": None if stage_serial is None else {
+                    "avg_launch_ms": round(stage_serial[dom], 5),
+                    "achieved": round(per_frame * B / (stage_serial[dom] * 1e-3) / 1e9, 3),
+                    "frac": round(per_frame * B / (stage_serial[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)},
             },
             "stage_ms": {k: round(v, 5) for k, v in stage.items()},
+            "stage_ms_one_chunk_in_flight": None if stage_serial is None else {k: round(v, 5) for k, v in stage_serial.items()},
             "pipeline_hbm": {
                 "algorithmic_bytes_per_frame": ab["total"],
                 "achieved_GBps": round(ab["total"] * value / world / 1e9, 3),

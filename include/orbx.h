@@ -111,6 +111,12 @@ int   orbx_async_device_buffers(orbx_t* h, int ticket, const orbx_keypoint_t** d
 int   orbx_async_download(orbx_t* h, int ticket, void* host_dst, const void* device_src, size_t bytes);
 int   orbx_wait(orbx_t* h, int ticket);
 
+/* A hipStream_t with a hardware queue of its own, for the `stream` argument of the *_device entry points when several chunks are kept in
+ * flight: ordinary HIP streams share a few hardware queues and two streams on one queue run in submission order, so chunks meant to
+ * overlap (one chunk's latency-bound quadtree / claim resolution beside another's FAST / blur / top-k) would not.  NULL on failure. */
+void* orbx_stream_create(int device_id);
+void  orbx_stream_destroy(void* stream);
+
 /* mvImagePyramid[level] (public member, include/ORBextractor.h:87; read by Frame::ComputeStereoMatches,
  * src/Frame.cc:950,1039-1058) of frame `frame` of the last extract call: copies the level to host memory.
  * dst may be NULL to query the size. */

@@ -34,6 +34,8 @@ SIGNATURES = {
     "orbx_set_tap_contraction": (_i, [_vp, _i]),
     "orbx_extract": (_i, [_vp, _vp, _i, _i, _sz, _i, _i, _vp, _vp, _i, _ip]),
     "orbx_extract_batch_device": (_i, [_vp, _vp, _i, _i, _i, _sz, _sz, _i, _i, _vp, _vp, _vp, _i, _vp]),
+    "orbx_stream_create": (_vp, [_i]),
+    "orbx_stream_destroy": (None, [_vp]),
     "orbx_host_alloc": (_vp, [_sz]),
     "orbx_host_free": (None, [_vp]),
     "orbx_set_async_depth": (_i, [_vp, _i]),

@@ -106,6 +106,7 @@ struct orbx_extractor {
   uint8_t*           hIn = nullptr;   // pinned take-off buffer of orbx_extract: the caller's (pageable) image is copied here first
   size_t             hInCap = 0;
   bool               overlapBlur = false;
+  int                overlapMode = 0;  // ORBX_OVERLAP_BLUR: 1 = blur beside FAST, 2 = blur beside the quadtree
   bool               profiling = false;
   int                tapMode = 1;  // orbx_set_tap_contraction
   // ---- streaming entry points (orbx_extract_async / orbx_wait): a ring of in-flight chunks.  Chunk k's upload runs on the
@@ -604,12 +605,14 @@ int orbx_extractor::run(const uint8_t* d_imgs, int B, int rows, int cols, size_t
     const int tx = (g.lv[l].w + kRsTileW - 1) / kRsTileW, ty = (g.lv[l].h + kRsTileH - 1) / kRsTileH;
     hipLaunchKernelGGL(k_resize_level, dim3(8 * tx, ty, (B + 7) / 8), dim3(256), 0, s, b, g, l, B);
   }
-  if (overlapBlur) {  // fork: the blur only needs the pyramid
+  auto forkBlur = [&]() -> int {  // the blur only needs the pyramid: side stream (a hardware queue of its own), joined before orientation
     HIP_TRY(hipEventRecord(evFork, s));
     HIP_TRY(hipStreamWaitEvent(stream2, evFork, 0));
     launchBlur(stream2);
     HIP_TRY(hipEventRecord(evJoin, stream2));
-  }
+    return 0;
+  };
+  if (overlapBlur && overlapMode == 1 && (rc = forkBlur())) return rc;  // beside FAST (both VALU-bound: measured, no gain)
   if (prof) HIP_TRY(hipEventRecord(ev[1], s));
   static const bool useCells = getenv("ORBX_FAST_CELLS") != nullptr;  // first-generation kernel (one workgroup per cell), kept for A/B runs
   if (!useCells) {
@@ -649,6 +652,8 @@ int orbx_extractor::run(const uint8_t* d_imgs, int B, int rows, int cols, size_t
     }
 #undef ORBX_LAUNCH_FAST
   }
+  // mode 2: beside the quadtree -- a latency-bound launch of 8 one-wave problems per CU that leaves the vector units idle
+  if (overlapBlur && overlapMode == 2 && (rc = forkBlur())) return rc;
   if (prof) HIP_TRY(hipEventRecord(ev[2], s));
   // level-major grid: the large levels start first and every level spreads over all XCDs
   hipLaunchKernelGGL(k_octree, dim3(B, g.nlevels), dim3(kOctThreads), octLdsBytes, s, b, g, octLdsNodeCap, octLdsPtsCap);
@@ -691,7 +696,8 @@ int orbx_create(orbx_t** out, int nfeatures, float scale_factor, int nlevels, in
   orbx_extractor* h = new orbx_extractor();
   h->nfeatures = nfeatures, h->nlevels = nlevels, h->iniTh = ini_th_fast, h->minTh = min_th_fast, h->scaleFactor = scale_factor;
   h->device = device_id;
-  h->overlapBlur = getenv("ORBX_OVERLAP_BLUR") && atoi(getenv("ORBX_OVERLAP_BLUR")) != 0;
+  h->overlapMode = getenv("ORBX_OVERLAP_BLUR") ? atoi(getenv("ORBX_OVERLAP_BLUR")) : 0;
+  h->overlapBlur = h->overlapMode != 0;
   // src/ORBextractor.cc:409-440, exact float sequence
   h->sf.resize(nlevels), h->sigma2.resize(nlevels), h->invSf.resize(nlevels), h->invSigma2.resize(nlevels), h->quota.resize(nlevels);
   h->sf[0] = 1.0f, h->sigma2[0] = 1.0f;
@@ -720,7 +726,8 @@ int orbx_create(orbx_t** out, int nfeatures, float scale_factor, int nlevels, in
   }
   // The side stream exists only when asked for: HIP streams share a handful of hardware queues, and every idle stream of a handle
   // makes it likelier that two streams which should overlap (kernels / copy-out) land on the same queue.
-  if (h->overlapBlur && (hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) != hipSuccess ||
+  const uint32_t allCus[8] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+  if (h->overlapBlur && (hipExtStreamCreateWithCUMask(&h->stream2, 8, allCus) != hipSuccess ||  // CU-masked stream = own hardware queue
                          hipEventCreateWithFlags(&h->evFork, hipEventDisableTiming) != hipSuccess ||
                          hipEventCreateWithFlags(&h->evJoin, hipEventDisableTiming) != hipSuccess)) {
     g_err = "hipStreamCreate/hipEventCreate (side stream) failed";
@@ -813,6 +820,31 @@ int orbx_set_input_resize(orbx_t* h, int new_cols, int new_rows) {
   if (!h || new_cols < 0 || new_rows < 0 || ((new_cols == 0) != (new_rows == 0))) return -2;
   h->preW = new_cols, h->preH = new_rows, h->preSrcW = h->preSrcH = 0;
   return 0;
+}
+
+// A HIP stream that owns its hardware queue.  HIP multiplexes ordinary streams onto a handful of hardware queues (least-referenced
+// first), and two streams that share one execute in submission order -- chunks that are meant to overlap (the latency-bound quadtree and
+// claim resolution of one chunk beside the VALU-bound FAST / blur / top-k of another) then do not.  A stream created with a CU mask
+// always gets a queue of its own; the mask enables every CU.
+void* orbx_stream_create(int device_id) {
+  if (hipSetDevice(device_id) != hipSuccess) return nullptr;
+  const uint32_t allCus[8] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+  hipStream_t    st = nullptr;
+  if (hipExtStreamCreateWithCUMask(&st, 8, allCus) != hipSuccess) {
+    (void)hipGetLastError();
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) {
+      g_err = "orbx_stream_create: hipStreamCreate failed";
+      return nullptr;
+    }
+  }
+  return (void*)st;
+}
+
+void orbx_stream_destroy(void* stream) {
+  if (stream) {
+    hipStreamSynchronize((hipStream_t)stream);
+    hipStreamDestroy((hipStream_t)stream);
+  }
 }
 
 int orbx_set_tap_contraction(orbx_t* h, int mode) {
