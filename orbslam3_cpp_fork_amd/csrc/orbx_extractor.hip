@@ -163,6 +163,7 @@ struct orbx_extractor {
   DevBuf<orbx::FastTile>     dTiles;      // k_fast_tiles: tile table + XCD-aware launch order
   DevBuf<int>                dTileOrder;
   int                        tileGrid = 0;
+  bool                       fastTwoStage = false;
   orbx::FastLds2             fastLds2{};
 
   // optional cv::resize of the input before extraction (System::TrackMonocular etc., src/System.cc:472-478)
@@ -455,7 +456,12 @@ int orbx_extractor::makeGeometry(int rows, int cols) {
     fl.mask1Off = alignUp(fl.candOff + 2 * fl.candCap, 16);
     fl.mask2Off = fl.mask1Off + 4 * maxCells * maxW;
     fl.cntOff   = fl.mask2Off + 4 * maxCells * maxW;
-    fl.total    = alignUp(fl.cntOff + 4 * (maxCells + 2), 16);
+    fl.stageOff = alignUp(fl.cntOff + 4 * (maxCells + 3), 16);
+    fastTwoStage = getenv("ORBX_FAST_TWO_STAGE") != nullptr;
+    // the staging slices and the corner list only exist in the two-stage form: 2 KB more LDS per workgroup costs a resident workgroup
+    fl.listCOff = fl.stageOff + (fastTwoStage ? 4 * 128 * 2 : 0);
+    fl.listCCap = fastTwoStage ? 512 : 0;
+    fl.total    = alignUp(fl.listCOff + 2 * fl.listCCap, 16);
     if (fl.total > 160 * 1024) {
       g_err = "FAST tile LDS plan exceeds 160 KB";
       return -2;
@@ -618,10 +624,17 @@ int orbx_extractor::run(const uint8_t* d_imgs, int B, int rows, int cols, size_t
   if (!useCells) {
     const int t1 = std::min(std::max(iniTh, 0), 255), t2 = std::min(std::max(minTh, 0), 255);
     static const int dbg = getenv("ORBX_DBG_SKIP_FAST") ? atoi(getenv("ORBX_DBG_SKIP_FAST")) : 0;  // ablation switch (tuning only)
-    if (al4)
-      hipLaunchKernelGGL((k_fast_tiles<true>), dim3(tileGrid, B), dim3(kFastTileThreads), fastLds2.total, s, b, g, dTiles.p, dTileOrder.p, t1, t2, fastLds2, dbg);
-    else
-      hipLaunchKernelGGL((k_fast_tiles<false>), dim3(tileGrid, B), dim3(kFastTileThreads), fastLds2.total, s, b, g, dTiles.p, dTileOrder.p, t1, t2, fastLds2, dbg);
+    // Default: all four opposite pairs in the dense pass.  ORBX_FAST_TWO_STAGE=1 selects the two-stage pre-test (N-S / E-W pairs densely,
+    // the diagonals on the compacted survivors, wave-local batching for the score): 33 % fewer dense instructions, but measured SLOWER
+    // (0.395 -> 0.429 ms per 256 VGA frames): the extra dependent LDS round trips of stage 2 cost more than the instructions saved.
+    const bool oneStage = !fastTwoStage;
+#define ORBX_LAUNCH_TILES(AL, TS) hipLaunchKernelGGL((k_fast_tiles<AL, TS>), dim3(tileGrid, B), dim3(kFastTileThreads), fastLds2.total, s, b, g, dTiles.p, dTileOrder.p, t1, t2, fastLds2, dbg)
+    if (al4) {
+      if (oneStage) ORBX_LAUNCH_TILES(true, false); else ORBX_LAUNCH_TILES(true, true);
+    } else {
+      if (oneStage) ORBX_LAUNCH_TILES(false, false); else ORBX_LAUNCH_TILES(false, true);
+    }
+#undef ORBX_LAUNCH_TILES
   } else
   {
     const int  per  = fastGrid / 8;  // order-table slots per XCD
