@@ -370,6 +370,8 @@ def run_stereo(args, c, rows, cols, nfeat):
         fence(c)
     gl, cl, kept, ev = ln.gl, ln.cl, ln.kept, ln.ev
     if c.rank != 0:
+        for x in lanes:
+            x.close()
         return
     stage = gl.stage_ms()
     stage["stereo_matches"] = float(np.mean([a.elapsed_time(b) for a, b in ev]))
@@ -394,6 +396,8 @@ def run_stereo(args, c, rows, cols, nfeat):
         out["cpu_baseline"] = cpu_baseline(None, nfeat, warm=4, timed=60, stereo=(L, R, mb, mbf))
         out["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)
     print(json.dumps(out), flush=True)
+    for x in lanes:
+        x.close()
 
 
 # ------------------------------------------------------------------------------------------------------------------------------
@@ -537,12 +541,13 @@ def main():
         def close(self):
             from orbslam3_cpp_fork_amd import _lib as _L
 
+            if not self.stream:
+                return
             torch.cuda.synchronize()
             self.ex.close()
             self.mt.close()
-            if self.stream:
-                _L.lib().orbx_stream_destroy(self.stream)
-                self.stream = None
+            _L.lib().orbx_stream_destroy(self.stream)
+            self.stream = None
 
         def drain(self):
             if self.pending is not None:
@@ -757,6 +762,14 @@ def main():
             out["cpu_baseline"] = cpu_baseline(frames_np, nfeat)
             out["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out), flush=True)
+    # orderly teardown while the runtime is alive (handles, then the streams they were driven on); nothing is left to finalizers
+    for ln in lanes:
+        if ln.stream:
+            ln.close()
+    if voc is not None:
+        voc.close() if hasattr(voc, "close") else None
+    del d_imgs, d_pairs
+    torch.cuda.synchronize()
     if world > 1:
         dist.destroy_process_group()
 

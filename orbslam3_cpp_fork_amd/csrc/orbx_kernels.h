@@ -104,17 +104,18 @@ __device__ __forceinline__ void resize_tile(const uint8_t* __restrict__ S, int s
     const bool colIn = (tid & 63) < nw4;
     const int  c     = min(tid & 63, nw4 - 1) * 4;
     uint32_t   v[6];  // nrow <= 24 = 6 rounds of 4 rows
+    const uint8_t* S0 = S + (long long)sya * sp + sxa;  // wave-uniform base; lanes add 32-bit offsets (no 64-bit multiply-adds per load)
     if (al4) {
 #pragma unroll
       for (int it = 0; it < 6; it++) {
         const int r = min((tid >> 6) + 4 * it, nrow - 1);
-        v[it]       = *reinterpret_cast<const uint32_t*>(S + (long long)(sya + r) * sp + sxa + c);  // may run past sw inside the aligned row
+        v[it]       = *reinterpret_cast<const uint32_t*>(S0 + (unsigned)(r * sp + c));  // may run past sw inside the aligned row
       }
     } else {
 #pragma unroll
       for (int it = 0; it < 6; it++) {
         const int      r = min((tid >> 6) + 4 * it, nrow - 1);
-        const uint8_t* p = S + (long long)(sya + r) * sp + sxa + c;
+        const uint8_t* p = S0 + (unsigned)(r * sp + c);
         v[it]            = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) v[it] |= (uint32_t)p[min(k, sw - 1 - sxa - c)] << (8 * k);
@@ -163,7 +164,7 @@ __device__ __forceinline__ void resize_tile(const uint8_t* __restrict__ S, int s
       out |= (uint32_t)(v & 0xff) << (8 * k);
     }
     // the destination pitch is a multiple of 64: lanes past dw write into the row's padding
-    *reinterpret_cast<uint32_t*>(D + (long long)dy * dp + dx) = out;
+    *reinterpret_cast<uint32_t*>(D + (unsigned)(dy * dp + dx)) = out;
   }
 }
 

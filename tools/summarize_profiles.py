@@ -28,6 +28,12 @@ if f:
         k = short(r["Name"])
         if k.startswith("k_"):
             out["kernels"].setdefault(k, {}).update(calls=int(r["Calls"]), avg_ms=float(r["AverageNs"]) / 1e6, pct=float(r["Percentage"]))
+f = one(d + "/trace_default/*/*kernel_stats.csv")
+if f:  # the default command (several chunks in flight)
+    for r in csv.DictReader(open(f)):
+        k = short(r["Name"])
+        if k.startswith("k_"):
+            out["kernels"].setdefault(k, {}).update(avg_ms_default_command=float(r["AverageNs"]) / 1e6, calls_default_command=int(r["Calls"]))
 for name, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
     f = one(d + "/%s/*/*counter_collection.csv" % sub)
     if not f:
@@ -60,4 +66,10 @@ for k, v in out["kernels"].items():
 for line in open(d + "/bench_trace.log"):
     if line.startswith('{"metric"'):
         out["bench"] = json.loads(line)
+try:
+    for line in open(d + "/bench_trace_default.log"):
+        if line.startswith('{"metric"'):
+            out["bench_default_command"] = json.loads(line)
+except OSError:
+    pass
 print(json.dumps(out, indent=1))
