@@ -698,6 +698,8 @@ const char* orbx_last_error(void) { return g_err.c_str(); }
 // Not part of include/orbx.h: the matcher and vocabulary translation units report through the same per-thread slot.
 void orbx_internal_set_error(const char* s) { g_err = s ? s : ""; }
 
+void* orbx_stream_create(int device_id);
+
 int orbx_create(orbx_t** out, int nfeatures, float scale_factor, int nlevels, int ini_th_fast, int min_th_fast, int device_id) {
   if (!out) return -2;
   *out = nullptr;
@@ -731,7 +733,9 @@ int orbx_create(orbx_t** out, int nfeatures, float scale_factor, int nlevels, in
     nDesiredFeaturesPerScale *= factor;
   }
   h->quota[nlevels - 1] = std::max(nfeatures - sumFeatures, 0);
-  hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+  // the handle's own stream owns a hardware queue (see orbx_stream_create): two handles driven side by side then really overlap
+  h->stream    = (hipStream_t)orbx_stream_create(device_id);
+  hipError_t e = h->stream ? hipSuccess : hipErrorUnknown;
   if (e != hipSuccess) {
     g_err = std::string("hipStreamCreate: ") + hipGetErrorString(e);
     delete h;
