@@ -385,18 +385,7 @@ struct WaveSort {
         last = cut;
       }
     }
-    // __final_insertion_sort: guarded insertion on the first 16 (or all), unguarded linear inserts after
-    const int guarded = n > 16 ? 16 : n;
-    for (int i = 1; i < n; i++) {
-      const unsigned long long val = get(i);
-      if (i < guarded && (val >> 16) < (get(0) >> 16)) {
-        shift_up_insert(0, i, val);  // move_backward(first, i, i + 1); *first = val
-      } else {
-        // __unguarded_linear_insert(i): position after the last record that is not greater than val
-        const int p = last_not_greater(0, i, val);
-        if (p + 1 < i) shift_up_insert(p + 1, i, val);
-      }
-    }
+    // __final_insertion_sort is done by the caller (ot_wave_sort_r): see there
     return true;
   }
 };
@@ -409,9 +398,39 @@ __device__ __forceinline__ bool ot_wave_sort_r(unsigned long long* buf, int n, i
 #pragma unroll
   for (int s = 0; s < R; s++) w.v[s] = (s * 64 + lane) < n ? buf[s * 64 + lane] : ~0ull;
   if (!w.run(n, stk)) return false;
+  // __final_insertion_sort (guarded insertion on the first 16 records, unguarded linear inserts after) without replaying its n
+  // serial insertions.  An insertion sort never moves a record past an equal one, so its result is THE stable sort of the array the
+  // introsort loop left behind; and that array is block-sorted -- every range the loop stopped on holds at most 16 records, all
+  // records of an earlier range are <= all records of a later one -- so a record ends inside its own range, at most 15 places from
+  // where it stands.  Hence: final position of record i = max(0, i - 15) + the number of records j of [i - 15, i + 15] with
+  // (key_j, j) < (key_i, i); every lane counts for its own records in parallel, then the records are scattered.
 #pragma unroll
   for (int s = 0; s < R; s++)
     if (s * 64 + lane < n) buf[s * 64 + lane] = w.v[s];
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  int pos[R];
+#pragma unroll
+  for (int s = 0; s < R; s++) {
+    const int                i  = s * 64 + lane;
+    const unsigned long long ki = w.v[s] >> 16;
+    const int                lo = i - 15 > 0 ? i - 15 : 0, hi = i + 15 < n - 1 ? i + 15 : n - 1;
+    int                      c  = 0;
+    if (i < n) {
+      for (int j = lo; j <= hi; j++) {
+        const unsigned long long kj = buf[j] >> 16;
+        c += (kj < ki || (kj == ki && j < i)) ? 1 : 0;
+      }
+    }
+    pos[s] = lo + c;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int s = 0; s < R; s++)
+    if (s * 64 + lane < n) buf[pos[s]] = w.v[s];
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
   return true;
 }
 

@@ -691,6 +691,8 @@ int orbx_extractor::run(const uint8_t* d_imgs, int B, int rows, int cols, size_t
   return 0;
 }
 
+static bool is_pinned(const void* p);
+
 extern "C" {
 
 const char* orbx_last_error(void) { return g_err.c_str(); }
@@ -933,7 +935,7 @@ int orbx_extract(orbx_t* h, const uint8_t* img, int rows, int cols, size_t step_
   const size_t rawBytes = (int)step_bytes == pitch ? (size_t)pitch * rows : step_bytes * (size_t)(rows - 1) + cols;
   static const bool directIn = getenv("ORBX_NO_PINNED_INPUT") != nullptr;
   const uint8_t*    hsrc     = img;
-  if (!directIn) {
+  if (!directIn && !is_pinned(img)) {  // an image that already lives in pinned memory (orbx_host_alloc) is uploaded from where it is
     if (h->hInCap < rawBytes) {
       if (h->hIn) hipHostFree(h->hIn);
       h->hIn = nullptr, h->hInCap = 0;
