@@ -263,12 +263,12 @@ struct HostCtx {
 #if defined(__HIPCC__)
 // ------------------------------------------------------------------------------------------------
 // Wave-parallel re-enactment of libstdc++ std::sort for n <= 256 records (one wave, record j lives in lane j % 64,
-// register slot j / 64).  It performs exactly the swaps / moves of ot_std_sort -- the element order after every
-// partition and every insertion is identical -- but the sequential scans of the library algorithm
-//   while (comp(*lo, pivot)) ++lo;      while (comp(pivot, *hi)) --hi;      while (comp(val, *next)) shift
-// are answered with one ballot + find-first/last-bit, and a run of shifts is one cross-lane move.  A single lane
-// walking the same algorithm through LDS needs ~2000 dependent LDS round trips (~100 us) for the ~100 nodes of a level;
-// this needs a few hundred wave instructions.  Falls back to the serial code if the heap-sort path would be taken.
+// register slot j / 64).  The array after every partition, and after the final insertion phase, is the one ot_std_sort
+// leaves -- equal keys included, which is what makes the quadtree's node order the reference's -- but neither phase is
+// walked serially: a partition's swaps are all found from two ballots per register slot (WaveSort::partition) and the
+// final insertion sort is a windowed stable rank (ot_wave_sort_r).  A single lane walking the library algorithm through
+// LDS needs ~2000 dependent LDS round trips (~100 us) for the ~100 nodes of a level; this needs ~60 wave instructions per
+// partition.  Falls back to the serial code if the heap-sort path would be taken.
 // ------------------------------------------------------------------------------------------------
 template <int R>
 struct WaveSort {
@@ -297,51 +297,76 @@ struct WaveSort {
     set(i, b);
     set(j, a);
   }
-  // smallest index in [from, to) whose record satisfies !(rec < pivot)   (rec compared on bits 63..16)
-  __device__ __forceinline__ int first_not_less(int from, int to, unsigned long long pivot) const {
+  // __unguarded_partition(first + 1, last, first) with all of its swaps done at once.  On the array as it stands before the loop let
+  // G = the positions of (first, last) whose record is not below the pivot, in ascending order (L_0 < L_1 < ...), and S = those whose
+  // record is not above it, in descending order (H_0 > H_1 > ...).  The library loop's k-th iteration stops its two scans at L_k and
+  // H_k -- neither scan can reach a position an earlier swap wrote before the loop ends -- and swaps them while L_k < H_k; with K such
+  // iterations it returns min(L_K, H_(K-1)).  For a position p:  a(p) = |G below p|,  c(p) = |S above p|;  p = L_k is swapped iff
+  // c(p) > a(p) (then k = a(p)), p = H_k iff a(p) > c(p) (k = c(p)) -- all from two ballots per register slot.  The exchange goes
+  // through `scratch` (>= last - first records; the sort buffer itself, unused while the records live in registers).
+  __device__ __forceinline__ int partition(int first, int last, unsigned long long pivot, unsigned long long* scratch) {
     const unsigned long long pk = pivot >> 16;
+    const int                s0 = (first + 1) >> 6, s1 = (last - 1) >> 6;
+    unsigned long long       mg[R], mh[R];
 #pragma unroll
     for (int s = 0; s < R; s++) {
-      const int                idx = s * 64 + lane;
-      const unsigned long long m   = __ballot(idx >= from && idx < to && !((v[s] >> 16) < pk));
-      if (m) return s * 64 + (__ffsll((long long)m) - 1);
+      mg[s] = 0, mh[s] = 0;
+      if (s >= s0 && s <= s1) {
+        const int                idx = s * 64 + lane;
+        const bool               in  = idx > first && idx < last;
+        const unsigned long long k   = v[s] >> 16;
+        mg[s] = __ballot(in && !(k < pk));
+        mh[s] = __ballot(in && !(pk < k));
+      }
     }
-    return to;
-  }
-  // largest index in [from, to) whose record satisfies !(pivot < rec)
-  __device__ __forceinline__ int last_not_greater(int from, int to, unsigned long long pivot) const {
-    const unsigned long long pk = pivot >> 16;
+    int a[R], c[R], acc = 0;
+#pragma unroll
+    for (int s = 0; s < R; s++) {
+      a[s] = acc + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mg[s] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mg[s], 0u));
+      acc += __popcll(mg[s]);
+    }
+    acc = 0;
 #pragma unroll
     for (int s = R - 1; s >= 0; s--) {
-      const int                idx = s * 64 + lane;
-      const unsigned long long m   = __ballot(idx >= from && idx < to && !(pk < (v[s] >> 16)));
-      if (m) return s * 64 + 63 - __clzll((long long)m);
+      const int below = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mh[s] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mh[s], 0u));
+      const int tot   = __popcll(mh[s]);
+      c[s] = acc + tot - below - (int)((mh[s] >> lane) & 1ull);
+      acc += tot;
     }
-    return from - 1;
-  }
-  // records a .. b-1 move one place up (to a+1 .. b), then record a = x      (move_backward + store)
-  __device__ __forceinline__ void shift_up_insert(int a, int b, unsigned long long x) {
-    unsigned long long prev[R];
+    bool left[R], right[R];
+    int  K = 0;
 #pragma unroll
     for (int s = 0; s < R; s++) {
-      // value of record (s*64 + lane - 1)
-      const unsigned long long own   = v[s];
-      const unsigned long long below = s > 0 ? v[s - 1] : 0ull;
-      const unsigned           lo1 = (unsigned)__shfl_up((int)(unsigned)own, 1, 64), hi1 = (unsigned)__shfl_up((int)(unsigned)(own >> 32), 1, 64);
-      const unsigned           lo2 = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)below, 63),
-                     hi2           = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(below >> 32), 63);
-      prev[s] = lane == 0 ? (((unsigned long long)hi2 << 32) | lo2) : (((unsigned long long)hi1 << 32) | lo1);
+      left[s]  = ((mg[s] >> lane) & 1ull) && c[s] > a[s];
+      right[s] = ((mh[s] >> lane) & 1ull) && a[s] > c[s];
+      K += __popcll(__ballot(left[s]));
     }
+    if (K > 0) {
+#pragma unroll
+      for (int s = 0; s < R; s++) {
+        if (left[s]) scratch[2 * a[s]] = v[s];
+        if (right[s]) scratch[2 * c[s] + 1] = v[s];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int s = 0; s < R; s++) {
+        if (left[s]) v[s] = scratch[2 * a[s] + 1];
+        if (right[s]) v[s] = scratch[2 * c[s]];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    int cut = last;
 #pragma unroll
     for (int s = 0; s < R; s++) {
-      const int idx = s * 64 + lane;
-      if (idx > a && idx <= b) v[s] = prev[s];
-      if (idx == a) v[s] = x;
+      const unsigned long long m = __ballot((((mg[s] >> lane) & 1ull) && a[s] == K) || (((mh[s] >> lane) & 1ull) && c[s] == K - 1));
+      if (m && cut == last) cut = s * 64 + (__ffsll((long long)m) - 1);
     }
+    return cut;
   }
 
-  // returns false if the depth limit was reached on a range > 16 (heap-sort path): caller falls back
-  __device__ __forceinline__ bool run(int n, int* stk) {  // stk: 3 x 64 ints in LDS (wave-uniform work list)
+  __device__ __forceinline__ bool run(int n, int* stk, unsigned long long* scratch) {  // stk: 3 x 64 ints in LDS (wave-uniform work list)
     int lg = 0;
     while ((1 << (lg + 1)) <= n) lg++;
     int *sf = stk, *sl = stk + 64, *sd = stk + 128, sp = 0;
@@ -370,16 +395,7 @@ struct WaveSort {
         else
           swap(first, ib);
         // __unguarded_partition(first + 1, last, first)
-        const unsigned long long pivot = get(first);
-        int                      lo = first + 1, hi = last;
-        while (true) {
-          lo = first_not_less(lo, last, pivot);        // while (comp(*lo, pivot)) ++lo;
-          hi = last_not_greater(first, hi, pivot);     // --hi; while (comp(pivot, *hi)) --hi;
-          if (!(lo < hi)) break;
-          swap(lo, hi);
-          ++lo;
-        }
-        const int cut = lo;
+        const int cut = partition(first, last, get(first), scratch);
         sf[sp] = cut, sl[sp] = last, sd[sp] = depth;
         sp++;
         last = cut;
@@ -397,7 +413,7 @@ __device__ __forceinline__ bool ot_wave_sort_r(unsigned long long* buf, int n, i
   w.lane = lane;
 #pragma unroll
   for (int s = 0; s < R; s++) w.v[s] = (s * 64 + lane) < n ? buf[s * 64 + lane] : ~0ull;
-  if (!w.run(n, stk)) return false;
+  if (!w.run(n, stk, buf)) return false;
   // __final_insertion_sort (guarded insertion on the first 16 records, unguarded linear inserts after) without replaying its n
   // serial insertions.  An insertion sort never moves a record past an equal one, so its result is THE stable sort of the array the
   // introsort loop left behind; and that array is block-sorted -- every range the loop stopped on holds at most 16 records, all
