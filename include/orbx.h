@@ -157,7 +157,8 @@ int orbx_debug_blurred_level(orbx_t* h, int frame, int level, uint8_t* dst, size
 int orbx_debug_level_candidates(orbx_t* h, int frame, int level, uint32_t* out, int cap);
 int orbx_debug_level_keypoints(orbx_t* h, int frame, int level, uint32_t* out, int cap);
 /* Tuning hook (set ORBX_DBG_OCT=1 before orbx_create): per (frame, level) of the last batch
- * {sort cycles, total cycles, division steps, sorts} of the quadtree kernel. Returns the number of values. */
+ * 8 values of the quadtree kernel: {sort cycles, total cycles, division steps, sorts, cycles in the passes over the
+ * points, in the per-node scans, in the node rewrite, in the root set-up}. Returns the number of values. */
 int orbx_debug_octree_times(orbx_t* h, long long* out, int cap);
 /* PMC calibration: stream nbytes of scratch memory with `width` (1, 4 or 16) bytes per lane per load. */
 int orbx_debug_calib_read(orbx_t* h, long long nbytes, int width);

@@ -85,7 +85,8 @@ struct OtArgs {
   // outputs
   uint32_t* outKp;  // kept candidates (same packing), list order
   int*      outCount;
-  long long* dbgT;  // optional diagnostic stamps (device tuning builds): [0] sort cycles, [1] total cycles, [2] division steps, [3] sorts
+  long long* dbgT;  // optional diagnostic stamps (device tuning builds): [0] sort cycles, [1] total cycles, [2] division steps, [3] sorts,
+                    // [4] cycles in the passes over the points, [5] per-node scans, [6] node rewrite, [7] root set-up
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -511,6 +512,10 @@ struct DevCtx {
     for (int w = 1; w < nw; w++) r = min(r, lds[w]);
     return r;
   }
+  __device__ void atomic_add(int* p, int v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  __device__ void atomic_max(unsigned long long* p, unsigned long long v) { __hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  __device__ int  atomic_load(const int* p) const { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  __device__ unsigned long long atomic_load(const unsigned long long* p) const { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 };
 #endif
 
@@ -520,7 +525,7 @@ struct DevCtx {
 struct WaveCtx {
   int  tid;  // lane
   int  nt;   // 64
-  int* lds;  // 192 ints of sort work list
+  int* lds;  // 80 unused ints (the multi-wave context keeps its per-wave totals there) followed by 192 ints of sort work list
   __device__ void sync() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
   __device__ Int4 scan4(const Int4& v, Int4* total) {
     Int4 inc = v;
@@ -545,7 +550,7 @@ struct WaveCtx {
     for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off, 64));
     return v;
   }
-  __device__ void sort(unsigned long long* buf, int n) { ot_wave_sort(buf, n, lds); }
+  __device__ void sort(unsigned long long* buf, int n) { ot_wave_sort(buf, n, lds + 80); }
   // counters live in LDS or in global memory (generic pointers); reads go through the same agent-scope path as the
   // atomics so that a line cached by an earlier plain load is never returned
   __device__ void atomic_add(int* p, int v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -606,6 +611,7 @@ OT_HD inline void ot_divide_step(CTX& c, const OtArgs& a, OtState& s, int nD, bo
   if (a.dbgT && c.tid == 0) a.dbgT[2] += 1;
   const int n = a.n;
   // -- A: count the points of every child of every flagged node (counters indexed by position in D)
+  long long tp = a.dbgT ? OT_CLOCK() : 0;
   for (int j = c.tid; j < nD; j += c.nt) a.childCnt[j] = Int4{{0, 0, 0, 0}};
   c.sync();
   for (int i = c.tid; i < n; i += c.nt) {
@@ -620,6 +626,7 @@ OT_HD inline void ot_divide_step(CTX& c, const OtArgs& a, OtState& s, int nD, bo
     }
   }
   c.sync();
+  if (a.dbgT && c.tid == 0) a.dbgT[4] += OT_CLOCK() - tp, tp = OT_CLOCK();
   // -- B: per processed node: children / multi-point children; exclusive offsets in processing order
   int dlo, dhi;
   ot_chunk(c, nD, &dlo, &dhi);
@@ -663,6 +670,7 @@ OT_HD inline void ot_divide_step(CTX& c, const OtArgs& a, OtState& s, int nD, bo
   // -- rank of the surviving nodes
   const OtIdx* dIndex = a.dIndex;  // kOtNone compares above every K
   ot_rank_flags(c, s.nNodes, [dIndex, K](int i) { return !(dIndex[i] < K); }, a.keptRank);
+  if (a.dbgT && c.tid == 0) a.dbgT[5] += OT_CLOCK() - tp, tp = OT_CLOCK();
   // -- C: write the new node array (children in reverse push order, then the survivors)
   for (int j = c.tid; j < K; j += c.nt) {
     const int    d  = a.D[j];
@@ -697,6 +705,7 @@ OT_HD inline void ot_divide_step(CTX& c, const OtArgs& a, OtState& s, int nD, bo
     if (!(di < K)) s.nodesNew[Ptot + a.keptRank[i]] = s.nodes[i];
   }
   c.sync();
+  if (a.dbgT && c.tid == 0) a.dbgT[6] += OT_CLOCK() - tp, tp = OT_CLOCK();
   // -- C': relabel the points
   for (int i = c.tid; i < n; i += c.nt) {
     const int lb = a.nodeOf[i], nd = lb & 0x3fff;
@@ -704,6 +713,7 @@ OT_HD inline void ot_divide_step(CTX& c, const OtArgs& a, OtState& s, int nD, bo
     a.nodeOf[i]  = (uint16_t)((di < K) ? a.childIdx[di].v[lb >> 14] : Ptot + a.keptRank[nd]);
   }
   c.sync();
+  if (a.dbgT && c.tid == 0) a.dbgT[4] += OT_CLOCK() - tp;
   const int newSize = Ptot + (s.nNodes - K);
   // swap ping-pong buffers; clear the flags of the new list
   {
@@ -764,6 +774,7 @@ OT_HD inline void ot_distribute(CTX& c, const OtArgs& a) {
     for (int i = c.tid; i < nn; i += c.nt) a.dIndex[i] = kOtNone;
     c.sync();
   }
+  if (a.dbgT && c.tid == 0) a.dbgT[7] += OT_CLOCK() - tStart;
   // ---- main loop (:608-733)
   bool bFinish = false;
   while (!bFinish) {

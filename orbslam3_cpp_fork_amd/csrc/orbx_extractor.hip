@@ -152,6 +152,7 @@ struct orbx_extractor {
   DevBuf<int4>    dOutIdx;
   DevBuf<uint16_t> dNodeOf, dD, dDIndex, dPushOff, dMultiOff, dKeptRank, dVA, dVB;
   int              octLdsNodeCap = 0, octLdsPtsCap = 0, octLdsBytes = 0;  // dynamic LDS plan of k_octree (makeGeometry)
+  int              octLatencyFrames = 8;  // up to this many frames per call the quadtree runs a workgroup, not a wave, per (frame, level)
   DevBuf<uint32_t>           dSlots, dCand, dLvlKp;
   DevBuf<orbx::OtNode>       dNodesA, dNodesB;
   DevBuf<orbx::Int4>         dChildCnt;
@@ -479,7 +480,7 @@ int orbx_extractor::makeGeometry(int rows, int cols) {
   {
     int maxCap = 0;
     for (int l = 0; l < nlevels; l++) maxCap = std::max(maxCap, g.lv[l].nodeCap);
-    const int fixed = kOctSortWork * 4, nodeBytes = maxCap * kOctNodeBytes;
+    const int fixed = kOctFixedInts * 4, nodeBytes = maxCap * kOctNodeBytes;
     if (fixed + nodeBytes + 2 * 512 <= 20224) {
       octLdsNodeCap = maxCap, octLdsBytes = 20224, octLdsPtsCap = (octLdsBytes - fixed - nodeBytes) / 2;
     } else if (fixed + nodeBytes + 2 * 4096 <= 40960) {
@@ -573,8 +574,8 @@ int orbx_extractor::run(const uint8_t* d_imgs, int B, int rows, int cols, size_t
   const FrameGeom& g = geom;
   Bufs             b = bufs;
   if (getenv("ORBX_DBG_OCT")) {
-    if (dDbgT.ensure((size_t)B * g.nlevels * 4)) return -3;
-    HIP_TRY(hipMemsetAsync(dDbgT.p, 0, (size_t)B * g.nlevels * 4 * sizeof(long long), s));
+    if (dDbgT.ensure((size_t)B * g.nlevels * 8)) return -3;
+    HIP_TRY(hipMemsetAsync(dDbgT.p, 0, (size_t)B * g.nlevels * 8 * sizeof(long long), s));
     b.dbgT = dDbgT.p;
   } else {
     b.dbgT = nullptr;
@@ -669,7 +670,10 @@ int orbx_extractor::run(const uint8_t* d_imgs, int B, int rows, int cols, size_t
   if (overlapBlur && overlapMode == 2 && (rc = forkBlur())) return rc;
   if (prof) HIP_TRY(hipEventRecord(ev[2], s));
   // level-major grid: the large levels start first and every level spreads over all XCDs
-  hipLaunchKernelGGL(k_octree, dim3(B, g.nlevels), dim3(kOctThreads), octLdsBytes, s, b, g, octLdsNodeCap, octLdsPtsCap);
+  if (B <= octLatencyFrames)
+    hipLaunchKernelGGL((k_octree<DevCtx, kOctThreadsLatency>), dim3(B, g.nlevels), dim3(kOctThreadsLatency), octLdsBytes, s, b, g, octLdsNodeCap, octLdsPtsCap);
+  else
+    hipLaunchKernelGGL((k_octree<WaveCtx, kOctThreads>), dim3(B, g.nlevels), dim3(kOctThreads), octLdsBytes, s, b, g, octLdsNodeCap, octLdsPtsCap);
   if (prof) HIP_TRY(hipEventRecord(ev[3], s));
   hipLaunchKernelGGL(k_layout, dim3(B), dim3(256), 0, s, b, g, lap0, lap1, d_counts, cap);
   if (prof) HIP_TRY(hipEventRecord(ev[4], s));
@@ -714,6 +718,7 @@ int orbx_create(orbx_t** out, int nfeatures, float scale_factor, int nlevels, in
   h->nfeatures = nfeatures, h->nlevels = nlevels, h->iniTh = ini_th_fast, h->minTh = min_th_fast, h->scaleFactor = scale_factor;
   h->device = device_id;
   h->overlapMode = getenv("ORBX_OVERLAP_BLUR") ? atoi(getenv("ORBX_OVERLAP_BLUR")) : 0;
+  if (getenv("ORBX_OCT_LATENCY_FRAMES")) h->octLatencyFrames = atoi(getenv("ORBX_OCT_LATENCY_FRAMES"));  // tuning: 0 = always one wave per problem
   h->overlapBlur = h->overlapMode != 0;
   // src/ORBextractor.cc:409-440, exact float sequence
   h->sf.resize(nlevels), h->sigma2.resize(nlevels), h->invSf.resize(nlevels), h->invSigma2.resize(nlevels), h->quota.resize(nlevels);
@@ -1470,12 +1475,12 @@ int orbx_debug_calib_read(orbx_t* h, long long nbytes, int width) {
   return 0;
 }
 
-// Tuning hook (ORBX_DBG_OCT=1): per (frame, level) {sort cycles, total cycles, division steps, sorts} of the last batch.
+// Tuning hook (ORBX_DBG_OCT=1): per (frame, level) 8 values of the last batch (see OtArgs::dbgT).
 int orbx_debug_octree_times(orbx_t* h, long long* out, int cap) {
   if (!h || !h->dDbgT.p) return -2;
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(hipDeviceSynchronize());
-  const int n = std::min(cap, h->lastB * h->nlevels * 4);
+  const int n = std::min(cap, h->lastB * h->nlevels * 8);
   HIP_TRY(hipMemcpy(out, h->dDbgT.p, (size_t)n * sizeof(long long), hipMemcpyDeviceToHost));
   return n;
 }

@@ -33,7 +33,7 @@ struct Bufs {
   const uint8_t* img0;
   long long      img0FrameStride;
   int            img0Pitch;
-  long long*     dbgT;  // optional quadtree timing stamps [frame][level][4] (ORBX_DBG_OCT=1)
+  long long*     dbgT;  // optional quadtree timing stamps [frame][level][8] (ORBX_DBG_OCT=1)
   uint8_t*       pyr;   // [B][pyrBytes]   levels >= 1
   uint8_t*       blur;  // [B][blurBytes]  all levels
   const int2*    xtab;  // resize tables: .x = source index, .y = a0 | a1 << 16 (Q11)
@@ -608,10 +608,10 @@ namespace orbx {
 // DistributeOctTree: one workgroup per (frame, level).  First gathers the per-cell candidate slots into
 // the feed order of the reference (cells row-major, row-major inside a cell), then runs octree_core.h.
 // ------------------------------------------------------------------------------------------------
-constexpr int kOctThreads   = 64;  // one wave per (frame, level): barriers degenerate to wave syncs
-constexpr int kOctNodeBytes = 64;  // LDS bytes per node over all node-level arrays (see ot_carve_lds)
-constexpr int kOctSortWork  = 192; // ints of sort work list
-
+constexpr int kOctThreads   = 64;   // throughput form: one wave per (frame, level), barriers degenerate to wave syncs
+constexpr int kOctThreadsLatency = 256;  // latency form (a handful of frames): a workgroup per (frame, level) shortens the passes over the points
+constexpr int kOctNodeBytes = 64;   // LDS bytes per node over all node-level arrays (see ot_carve_lds)
+constexpr int kOctFixedInts = 80 + 192;  // per-wave totals of the multi-wave context + the sort work list
 __device__ __forceinline__ void octree_args(const Bufs& b, const FrameGeom& g, int f, int level, OtArgs* a) {
   const LevelGeom& L  = g.lv[level];
   const long long  po = (long long)f * g.totalSlots + L.slotBase;
@@ -631,7 +631,7 @@ __device__ __forceinline__ void octree_args(const Bufs& b, const FrameGeom& g, i
   a->keptRank = b.keptRank + no, a->vA = b.vA + no, a->vB = b.vB + no;
   a->outKp    = b.lvlKp + (long long)f * g.totalKp + L.kpBase;
   a->outCount = b.lvlCount + (long long)f * g.nlevels + level;
-  a->dbgT     = b.dbgT ? b.dbgT + ((long long)f * g.nlevels + level) * 4 : nullptr;
+  a->dbgT     = b.dbgT ? b.dbgT + ((long long)f * g.nlevels + level) * 8 : nullptr;
 }
 
 // Carve the node-level arrays (and, if they fit, the point labels) out of `lds`.  Layout per node: 2 x OtNode (24),
@@ -655,14 +655,15 @@ __device__ __forceinline__ void ot_carve_lds(OtArgs* a, unsigned char* lds, int 
 }
 
 // ldsNodeCap: nodes the dynamic LDS block was sized for (0 = everything stays in global memory); ldsPtsCap: point labels.
-__global__ __launch_bounds__(kOctThreads) void k_octree(Bufs b, FrameGeom g, int ldsNodeCap, int ldsPtsCap) {
-  static_assert(kOctThreads == 64, "k_octree runs one wave per (frame, level)");
+// CTX = WaveCtx (64 threads) or DevCtx (NT threads): the same algorithm, its passes spread over one or NT / 64 waves.
+template <class CTX, int NT>
+__global__ __launch_bounds__(NT) void k_octree(Bufs b, FrameGeom g, int ldsNodeCap, int ldsPtsCap) {
   extern __shared__ __align__(16) unsigned char ldsDyn[];
-  int*             scratch = reinterpret_cast<int*>(ldsDyn);  // sort work list
+  int*             scratch = reinterpret_cast<int*>(ldsDyn);
   const int        level = blockIdx.y, f = blockIdx.x;
   const LevelGeom& L = g.lv[level];
-  WaveCtx          c;
-  c.tid = threadIdx.x, c.nt = 64, c.lds = scratch;
+  CTX              c;
+  c.tid = threadIdx.x, c.nt = NT, c.lds = scratch;
   OtArgs a;
   octree_args(b, g, f, level, &a);
   // feed order: exclusive scan of the cell counts, then copy the slots
@@ -698,10 +699,10 @@ __global__ __launch_bounds__(kOctThreads) void k_octree(Bufs b, FrameGeom g, int
   // accesses, which pay the flat-address path on every node-array access of this latency-bound kernel).
   if (L.nodeCap <= ldsNodeCap) {
     if (n <= ldsPtsCap) {
-      ot_carve_lds(&a, ldsDyn + kOctSortWork * 4, L.nodeCap, true);
+      ot_carve_lds(&a, ldsDyn + kOctFixedInts * 4, L.nodeCap, true);
       ot_distribute(c, a);
     } else {
-      ot_carve_lds(&a, ldsDyn + kOctSortWork * 4, L.nodeCap, false);
+      ot_carve_lds(&a, ldsDyn + kOctFixedInts * 4, L.nodeCap, false);
       ot_distribute(c, a);
     }
   } else {
@@ -711,7 +712,7 @@ __global__ __launch_bounds__(kOctThreads) void k_octree(Bufs b, FrameGeom g, int
 
 // stand-alone quadtree on caller-supplied candidates (parity hook)
 __global__ __launch_bounds__(kOctThreads) void k_octree_only(OtArgs a) {
-  __shared__ int scratch[kOctSortWork];
+  __shared__ int scratch[kOctFixedInts];
   WaveCtx        c;
   c.tid = threadIdx.x, c.nt = 64, c.lds = scratch;
   ot_distribute(c, a);

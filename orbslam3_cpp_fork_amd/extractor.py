@@ -5,6 +5,7 @@ vLappingArea)` -> returns monoIndex, fills keypoints/descriptors), same getters,
 (-1 on an empty image).  The compute runs in the HIP kernels of liborbx.so; nothing here computes.
 """
 import ctypes as C
+import sys
 
 import numpy as np
 
@@ -192,10 +193,8 @@ def pinned_array(shape, dtype):
         def __init__(self, p):
             self.p = p
 
-        def __del__(self):
-            import sys
-
-            if sys is None or sys.is_finalizing():  # at interpreter shutdown the HIP runtime may already be gone: the OS reclaims the pages
+        def __del__(self, _finalizing=sys.is_finalizing):
+            if _finalizing():  # at interpreter shutdown the HIP runtime may already be gone: the OS reclaims the pages
                 return
             try:
                 _lib.lib().orbx_host_free(C.c_void_p(self.p))

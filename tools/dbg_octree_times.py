@@ -12,8 +12,10 @@ kps = torch.zeros((B, cap, 7), device="cuda"); desc = torch.zeros((B, cap, 32), 
 for _ in range(2):
     ex.extract_batch_device(d, B, rows, cols, cols, rows * cols, kps, desc, cnt, cap, (0, 1000), stream=ts.cuda_stream)
 torch.cuda.synchronize()
-out = np.zeros(B * 8 * 4, np.int64)
+out = np.zeros(B * 8 * 8, np.int64)
 n = _lib.lib().orbx_debug_octree_times(ex._h, out.ctypes.data_as(C.c_void_p), len(out))
-t = out[:n].reshape(B, 8, 4)
+t = out[:n].reshape(B, 8, 8)
 for l in range(8):
-    print("level %d: sort cyc %8.0f  total cyc %8.0f  steps %.1f sorts %.1f  cands %s" % (l, t[:, l, 0].mean(), t[:, l, 1].mean(), t[:, l, 2].mean(), t[:, l, 3].mean(), ""))
+    m = t[:, l].mean(0)
+    print("level %d: total %7.0f cyc = sort %6.0f + points %6.0f + scans %6.0f + rewrite %6.0f + roots %6.0f + rest %6.0f;  steps %.1f sorts %.1f" % (
+        l, m[1], m[0], m[4], m[5], m[6], m[7], m[1] - m[0] - m[4] - m[5] - m[6] - m[7], m[2], m[3]))
