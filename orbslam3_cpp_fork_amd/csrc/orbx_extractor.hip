@@ -452,6 +452,7 @@ int orbx_extractor::makeGeometry(int rows, int cols) {
     const int region = alignUp(maxTileBytes + 32, 16);
     FastLds2  fl{};
     fl.scoreOff = alignUp(16 + region, 16);
+    fl.scoreBytes = region;
     fl.candOff  = fl.scoreOff + region;
     fl.candCap  = getenv("ORBX_FAST_CAND_CAP") ? atoi(getenv("ORBX_FAST_CAND_CAP")) : 2048;
     fl.mask1Off = alignUp(fl.candOff + 2 * fl.candCap, 16);

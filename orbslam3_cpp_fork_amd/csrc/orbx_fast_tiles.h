@@ -32,7 +32,7 @@ struct FastTile {  // host-built (orbx_extractor::makeGeometry), read with scala
 };
 
 struct FastLds2 {  // dynamic LDS plan (bytes); the pixel tile sits at offset 16
-  int scoreOff, candOff, candCap, mask1Off, mask2Off, cntOff, total;
+  int scoreOff, scoreBytes, candOff, candCap, mask1Off, mask2Off, cntOff, total;
   int stageOff, listCOff, listCCap;  // two-stage form: 4 x 128 u16 staging entries (one slice per wave), list of scored corners for NMS
 };
 
@@ -76,7 +76,8 @@ __global__ __launch_bounds__(kFastTileThreads) void k_fast_tiles(Bufs b, FrameGe
   const int tix = order[blockIdx.x];
   if (tix < 0) return;
   const FastTile T   = tiles[tix];
-  const int      f   = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int      f   = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+  const int      wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: row addresses and per-cell loops are computed on the scalar unit
   uint8_t*       tile  = fastLds2 + 16;
   uint8_t*       score = fastLds2 + fl.scoreOff;
   unsigned short* cand = reinterpret_cast<unsigned short*>(fastLds2 + fl.candOff);
@@ -101,15 +102,18 @@ __global__ __launch_bounds__(kFastTileThreads) void k_fast_tiles(Bufs b, FrameGe
     const int  col = lane, tw = (T.ox3 - 3) + T.IW + 6;  // bytes per staged row that belong to the image row
     const bool cin = col < T.tw4;
     const int  cb  = min(col, T.tw4 - 1) * 4;             // byte column (clamped: every lane loads, only staged columns are stored)
-    for (int r0 = wave; r0 < T.th; r0 += 16) {
-      uint32_t v[4];
+    // kStageRows loads in flight per lane (a tile is ~45 rows: one trip of the loop, one exposure to the memory latency)
+    constexpr int kStageRows = 12;
+    for (int r0 = wave; r0 < T.th; r0 += 4 * kStageRows) {
+      uint32_t v[kStageRows];
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
+      for (int k = 0; k < kStageRows; k++) {
         const int      r = min(r0 + 4 * k, T.th - 1);
-        const uint8_t* p = src + (unsigned)(r * sp + cb);  // uniform base + 32-bit lane offset
+        const uint8_t* p = src + (long long)r * sp;  // uniform row base (scalar unit) + 32-bit lane offset
         if (AL4) {
-          v[k] = *reinterpret_cast<const uint32_t*>(p);
+          v[k] = *reinterpret_cast<const uint32_t*>(p + (unsigned)cb);
         } else {
+          p += cb;
           uint32_t u = p[0];
           if (cb + 1 < tw) u |= (uint32_t)p[1] << 8;
           if (cb + 2 < tw) u |= (uint32_t)p[2] << 16;
@@ -118,14 +122,13 @@ __global__ __launch_bounds__(kFastTileThreads) void k_fast_tiles(Bufs b, FrameGe
         }
       }
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
+      for (int k = 0; k < kStageRows; k++) {
         const int r = r0 + 4 * k;
-        if (cin && r < T.th) {
-          *reinterpret_cast<uint32_t*>(tile + r * P + col * 4)  = v[k];
-          *reinterpret_cast<uint32_t*>(score + r * P + col * 4) = 0;
-        }
+        if (cin && r < T.th) *reinterpret_cast<uint32_t*>(tile + r * P + col * 4) = v[k];
       }
     }
+    // the score map (same shape as the tile, 16-byte aligned, a multiple of 16 bytes long) is cleared with 16-byte stores
+    for (int i = tid * 16, n = min(fl.scoreBytes, (T.th * P + 15) & ~15); i < n; i += kFastTileThreads * 16) *reinterpret_cast<uint4*>(score + i) = make_uint4(0, 0, 0, 0);
     const int nmask = T.ncells * T.W;
     for (int i = tid; i < nmask; i += kFastTileThreads) mask1[i] = 0, mask2[i] = 0;
     if (tid <= T.ncells + 1) cnt[tid] = 0;
