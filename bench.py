@@ -413,6 +413,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive pass (host frames in, host records out)")
     ap.add_argument("--no-match", action="store_true", help="extract only")
+    ap.add_argument("--c-gather", action="store_true", help="multi-rank runs: gather the records with orbx_gather (RCCL behind the C ABI) instead of torch.distributed.gather")
     ap.add_argument("--lanes", type=int, default=3, help="chunks in flight, each with its own handles, buffers and a HIP stream that owns a hardware queue: "
                     "the latency-bound kernels of one chunk (quadtree, claim resolution) run beside the VALU-bound ones of the others; 1 = strictly serial")
     ap.add_argument("--rows", action="store_true", help="measure the SURVEY 8(f) rows N1-N3 (device path vs the CPU restatement on the same inputs) "
@@ -494,6 +495,16 @@ def main():
             assert self.stream
             self.tstream = torch.cuda.ExternalStream(self.stream, device=dev)
             self.gather = shard.RecordGather(B, self.cap, dev, world, rank, host_staged=(backend != "nccl")) if world > 1 else None
+            self.cgather = None
+            if args.c_gather and world > 1 and backend == "nccl":
+                # the same exchange through the C ABI (orbx_comm_create / orbx_gather): RCCL called by liborbx.so, no pack, enqueued on
+                # the chunk's own stream.  The rendezvous token travels over the process group torch already has.
+                def exchange(tok):
+                    box = [tok]
+                    dist.broadcast_object_list(box, src=0)
+                    return box[0]
+
+                self.cgather, self.gather = shard.CommGather(B, self.cap, local_rank, world, rank, exchange=exchange), None
             self.pending = None
             self.match_ev = []
             self.bow_ev = []
@@ -530,6 +541,8 @@ def main():
                     if timed:
                         e1.record()
                         self.match_ev.append((e0, e1))
+                if self.cgather is not None:
+                    self.cgather(self.d_kps, self.d_desc, self.d_cnt, stream=self.stream)
                 if self.gather is not None:
                     # Asynchronous RCCL gather on the collective's own stream.  It reads the packed copy of the records, not the
                     # extractor's buffers, so the NEXT chunk's extraction and matching run beside it; only the next pack has to
@@ -739,7 +752,7 @@ def main():
                 "nfeatures": nfeat,
                 "nlevels": 8,
                 "parallelism": ("8 cameras dealt over %d rank(s) (%d per GPU)" % (world, RIG_CAMERAS // world) if rig else "frames sharded by camera, %d rank(s)" % world)
-                               + (", RCCL gather of keypoints+descriptors to rank 0" if world > 1 else ""),
+                               + ((", RCCL gather of keypoints+descriptors to rank 0" + (" (orbx_gather, C ABI)" if args.c_gather and backend == "nccl" else "")) if world > 1 else ""),
                 "keypoints_per_frame": float(cnt[:, 0].mean()),
                 "matches_per_frame": float(nm.mean()) if not args.no_match else None,
             },

@@ -117,6 +117,28 @@ int   orbx_wait(orbx_t* h, int ticket);
 void* orbx_stream_create(int device_id);
 void  orbx_stream_destroy(void* stream);
 
+/* The one exchange step of the path: when a rig's cameras are extracted on several GPUs -- one process per GPU, each
+ * with its own orbx_t -- the fixed-capacity records of every rank's cameras are gathered onto the rank that tracks
+ * (src/Tracking.cc:1329-1608 consumes all cameras of a step).  RCCL underneath, opened lazily (no RCCL dependency for hosts that never
+ * create a communicator); direct sends to the root over each peer's own xGMI link in one group, no ring, no staging.
+ *   orbx_comm_unique_id  one rank (normally 0) creates the 128-byte rendezvous token; the host hands it to every rank by its own
+ *                        means (file, socket, MPI, environment).
+ *   orbx_comm_create     collective: every rank calls it with the same token, its rank and the number of ranks.
+ *   orbx_gather          collective: rank r contributes its nframes records (device arrays laid out as orbx_extract_batch_device
+ *                        writes them: d_kps [nframes][cap], d_desc [nframes][cap][32], d_counts [nframes][2]); the root receives
+ *                        d_all_kps [nranks][nframes][cap], d_all_desc [nranks][nframes][cap][32], d_all_counts [nranks][nframes][2]
+ *                        (ignored on the other ranks, may be NULL there).  Enqueued on `stream` (a hipStream_t); returns at once.
+ * Return 0, -2 (bad arguments), -3 (RCCL / HIP error; orbx_last_error has the text). */
+#define ORBX_UNIQUE_ID_BYTES 128
+typedef struct orbx_comm orbx_comm_t;
+int  orbx_comm_unique_id(void* id_out);
+int  orbx_comm_create(orbx_comm_t** out, int device_id, int rank, int nranks, const void* unique_id);
+void orbx_comm_destroy(orbx_comm_t* c);
+int  orbx_comm_rank(const orbx_comm_t* c);
+int  orbx_comm_size(const orbx_comm_t* c);
+int  orbx_gather(orbx_comm_t* c, const orbx_keypoint_t* d_kps, const uint8_t* d_desc, const int* d_counts, int nframes, int cap,
+                 orbx_keypoint_t* d_all_kps, uint8_t* d_all_desc, int* d_all_counts, int root, void* stream);
+
 /* mvImagePyramid[level] (public member, include/ORBextractor.h:87; read by Frame::ComputeStereoMatches,
  * src/Frame.cc:950,1039-1058) of frame `frame` of the last extract call: copies the level to host memory.
  * dst may be NULL to query the size. */

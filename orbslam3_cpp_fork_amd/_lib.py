@@ -36,6 +36,12 @@ SIGNATURES = {
     "orbx_extract_batch_device": (_i, [_vp, _vp, _i, _i, _i, _sz, _sz, _i, _i, _vp, _vp, _vp, _i, _vp]),
     "orbx_stream_create": (_vp, [_i]),
     "orbx_stream_destroy": (None, [_vp]),
+    "orbx_comm_unique_id": (_i, [_vp]),
+    "orbx_comm_create": (_i, [C.POINTER(_vp), _i, _i, _i, _vp]),
+    "orbx_comm_destroy": (None, [_vp]),
+    "orbx_comm_rank": (_i, [_vp]),
+    "orbx_comm_size": (_i, [_vp]),
+    "orbx_gather": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _vp]),
     "orbx_host_alloc": (_vp, [_sz]),
     "orbx_host_free": (None, [_vp]),
     "orbx_set_async_depth": (_i, [_vp, _i]),

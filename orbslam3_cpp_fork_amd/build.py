@@ -9,7 +9,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "liborbx.so")
-HIP_SOURCES = ["orbx_extractor.hip", "orbx_matcher.hip", "orbx_vocab.hip", "orbx_calib.hip"]
+HIP_SOURCES = ["orbx_extractor.hip", "orbx_matcher.hip", "orbx_vocab.hip", "orbx_calib.hip", "orbx_comm.hip"]
 HOST_SOURCES = ["orbx_hostmodel.cpp"]
 HEADERS = ["orbx_kernels.h", "orbx_fast_tiles.h", "orbx_geom.h", "octree_core.h", "orb_sincosf_port.h", "orb_pattern.inc", "../../include/orbx.h"]
 # -ffp-contract=off: float expressions must evaluate as the reference writes them (no FMA fusion).
@@ -84,7 +84,7 @@ def build(force=False, verbose=False):
     except Exception:
         pass
     rpaths.append("/opt/rocm/lib")
-    cmd = ["g++", "-shared", "-fPIC", "-o", OUT] + objs + ["-L" + stubdir, "-lamdhip64", "-lpthread"] + ["-Wl,--disable-new-dtags"] + ["-Wl,-rpath," + r for r in rpaths]
+    cmd = ["g++", "-shared", "-fPIC", "-o", OUT] + objs + ["-L" + stubdir, "-lamdhip64", "-lpthread", "-ldl"] + ["-Wl,--disable-new-dtags"] + ["-Wl,-rpath," + r for r in rpaths]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

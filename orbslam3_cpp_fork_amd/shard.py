@@ -70,3 +70,63 @@ class RecordGather:
         kps = a[self._o1: self._o2].view(KP_DTYPE).reshape(self.B, self.cap)
         desc = a[self._o2:].reshape(self.B, self.cap, 32)
         return cnt, kps, desc
+
+
+class CommGather:
+    """The same exchange step through the C ABI (orbx_comm_create / orbx_gather, csrc/orbx_comm.hip): RCCL called from the
+    library itself, as a C++ host would use it -- no pack, the three record arrays go out as they lie in HBM.
+
+    The 128-byte rendezvous token is created by `root` and handed to the other ranks through `exchange(token_bytes_or_None) ->
+    token_bytes` (a callable the host supplies: a torch.distributed / MPI broadcast, a file ...); with world == 1 nothing is
+    exchanged."""
+
+    def __init__(self, B, cap, device_index, world, rank, root=0, exchange=None):
+        import ctypes as C
+
+        import torch
+
+        from . import _lib
+
+        self.B, self.cap, self.world, self.rank, self.root = B, cap, world, rank, root
+        L = _lib.lib()
+        tok = (C.c_uint8 * 128)()
+        if rank == root:
+            _lib.check(L.orbx_comm_unique_id(tok), "orbx_comm_unique_id")
+        if world > 1:
+            if exchange is None:
+                raise ValueError("CommGather: world > 1 needs an exchange callable for the rendezvous token")
+            data = exchange(bytes(tok) if rank == root else None)
+            tok = (C.c_uint8 * 128).from_buffer_copy(data)
+        self._h = C.c_void_p()
+        _lib.check(L.orbx_comm_create(C.byref(self._h), device_index, rank, world, tok), "orbx_comm_create")
+        dev = "cuda:%d" % device_index
+        if rank == root:
+            self.all_kps = torch.empty((world, B, cap, 7), dtype=torch.float32, device=dev)
+            self.all_desc = torch.empty((world, B, cap, 32), dtype=torch.uint8, device=dev)
+            self.all_cnt = torch.empty((world, B, 2), dtype=torch.int32, device=dev)
+        else:
+            self.all_kps = self.all_desc = self.all_cnt = None
+
+    def __call__(self, d_kps, d_desc, d_cnt, stream=0):
+        """Enqueue the gather on `stream` (a raw hipStream_t value); on the root the result lands in all_kps / all_desc / all_cnt."""
+        import ctypes as C
+
+        from . import _lib
+
+        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        _lib.check(_lib.lib().orbx_gather(self._h, p(d_kps), p(d_desc), p(d_cnt), self.B, self.cap, p(self.all_kps), p(self.all_desc), p(self.all_cnt),
+                                          self.root, C.c_void_p(stream)), "orbx_gather")
+        return self.all_kps, self.all_desc, self.all_cnt
+
+    def close(self):
+        from . import _lib
+
+        if self._h:
+            _lib.lib().orbx_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

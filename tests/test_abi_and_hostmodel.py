@@ -183,6 +183,12 @@ def test_bad_arguments_are_rejected_before_the_device():
     assert L.orbx_image_bounds(640, 480, None, None, 0, _lib.ptr(one)) == -2
     assert L.orbx_image_bounds(640, 480, _lib.ptr(one), None, 3, _lib.ptr(one)) == -2  # coefficients promised but missing
     assert L.orbx_set_input_resize(None, 600, 350) == -2
+    # the gather of SURVEY 8(e): argument errors are caught before RCCL is even opened
+    assert L.orbx_comm_unique_id(None) == -2
+    assert L.orbx_comm_create(None, 0, 0, 1, None) == -2
+    assert L.orbx_comm_create(C.byref(h), 0, 2, 2, _lib.ptr(one)) == -2  # rank outside [0, nranks)
+    assert L.orbx_gather(None, None, None, None, 1, 16, None, None, None, 0, None) == -2
+    assert L.orbx_comm_rank(None) == -1 and L.orbx_comm_size(None) == -1
     assert L.orbx_undistort_keypoints(None, None, 0, None, None, 0, None) == -2
     assert L.orbm_search_by_projection(None, None, None, None, None, None, None, 0, None, None, None, None, 0, None, 8, 15.0, 0, 0.0, 0.0, 1.0, 0.0, 1.0, 100, 1, None, None) == -2
     assert L.orbm_search_by_projection_map(None, None, None, None, None, None, None, 0, None, None, None, None, 0, None, 8, 0.8, 0.0, 1.0, 0.0, 1.0, 100, None, None) == -2

@@ -232,3 +232,31 @@ def test_min_threshold_above_ini_threshold(oracle, vga_frame):
     rc, k, d = ex(vga_frame, None, (0, 0))
     rc0, k0, d0 = oex(vga_frame, (0, 0))
     assert rc == rc0 and len(k) == len(k0) and (k.view(np.uint32) == k0.view(np.uint32)).all() and (d == d0).all()
+
+
+@pytest.mark.gpu
+def test_gather_through_the_c_abi_single_rank():
+    """orbx_comm_create / orbx_gather (csrc/orbx_comm.hip) with one rank: RCCL is opened, the communicator is built, and the root's
+    slice of the gathered arrays is the rank's own records.  (More ranks need more GPUs than a test box has: RCCL refuses two
+    ranks on one device.  The N-rank exchange is covered on CPU by tests/test_shard_gloo.py through the torch.distributed form.)"""
+    import torch
+
+    from orbslam3_cpp_fork_amd import shard, synth
+    from orbslam3_cpp_fork_amd.extractor import ORBextractor
+
+    B, rows, cols = 3, 240, 320
+    fr = synth.make_stream(rows, cols, B, camera_idx=2)
+    ex = ORBextractor(500)
+    cap = ex.max_keypoints(rows, cols)
+    d = torch.from_numpy(fr).cuda()
+    kps = torch.zeros((B, cap, 7), device="cuda")
+    desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
+    cnt = torch.zeros((B, 2), dtype=torch.int32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    ex.extract_batch_device(d, B, rows, cols, cols, rows * cols, kps, desc, cnt, cap, (0, 1000), stream=st)
+    g = shard.CommGather(B, cap, 0, 1, 0)
+    ak, ad, ac = g(kps, desc, cnt, stream=st)
+    torch.cuda.synchronize()
+    assert int(cnt[:, 0].min()) > 100
+    assert torch.equal(ac[0], cnt) and torch.equal(ad[0], desc) and torch.equal(ak[0].view(torch.int32), kps.view(torch.int32))
+    g.close()
