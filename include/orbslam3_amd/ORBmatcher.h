@@ -36,13 +36,16 @@ class ORBmatcher {
   // DBoW2::FeatureVector is std::map<NodeId, std::vector<unsigned int>>
   typedef std::map<unsigned int, std::vector<unsigned int>> FeatureVector;
 
-  // Core of SearchByBoW(KeyFrame* pKF, Frame& F, vpMapPointMatches) (src/ORBmatcher.cc:237-421, F.Nleft == -1):
+  // Core of SearchByBoW(KeyFrame* pKF, Frame& F, vpMapPointMatches) (src/ORBmatcher.cc:237-421):
   // kfHasMapPoint[i] = (vpMapPointsKF[i] && !isBad()); matchKFofF[j] = KeyFrame feature whose MapPoint frame
   // feature j receives, -1 = NULL.  strictLess selects the KeyFrame-KeyFrame overload's `< TH_LOW` (:864).
+  // fNleft = F.Nleft: -1 for a one-camera frame; otherwise descF / angleF hold the left keys [0, Nleft) followed by the right keys
+  // (as F.mDescriptors does) and the two-camera branch (:305-333, 362-389) runs -- a KeyFrame feature may then hand its MapPoint to
+  // a left AND a right frame feature, so matchFofKF is not filled in that mode (fHasMapPoint / strictLess do not apply either).
   int SearchByBoWArrays(const orbx_cv::Mat& descKF, const std::vector<float>& angleKF, const FeatureVector& fvKF,
                         const std::vector<unsigned char>& kfHasMapPoint, const orbx_cv::Mat& descF, const std::vector<float>& angleF,
                         const FeatureVector& fvF, std::vector<int>& matchKFofF, const std::vector<unsigned char>* fHasMapPoint = nullptr,
-                        bool strictLess = false, std::vector<int>* matchFofKF = nullptr) {
+                        bool strictLess = false, std::vector<int>* matchFofKF = nullptr, int fNleft = -1) {
     std::vector<int> qoff(1, 0), qidx, toff(1, 0), tidx;
     FeatureVector::const_iterator a = fvKF.begin(), b = fvF.begin();
     while (a != fvKF.end() && b != fvF.end()) {  // merge walk of :259-399
@@ -62,6 +65,13 @@ class ORBmatcher {
     const int ng = (int)qoff.size() - 1;
     if (ng == 0) return 0;
     std::vector<uint8_t> q = pack(descKF), t = pack(descF);
+    if (fNleft != -1) {
+      int n2 = orbm_match_groups_two_cameras(h_, q.data(), descKF.rows, t.data(), descF.rows, fNleft, ng, qoff.data(), qidx.data(), toff.data(),
+                                             tidx.data(), kfHasMapPoint.empty() ? nullptr : kfHasMapPoint.data(), angleKF.data(), angleF.data(), TH_LOW,
+                                             mfNNratio, mbCheckOrientation ? 1 : 0, matchKFofF.data());
+      if (n2 <= -2) throw std::runtime_error(std::string("orbm_match_groups_two_cameras: ") + orbx_last_error());
+      return n2;
+    }
     int n = orbm_match_groups(h_, q.data(), descKF.rows, t.data(), descF.rows, ng, qoff.data(), qidx.data(), toff.data(), tidx.data(),
                               kfHasMapPoint.empty() ? nullptr : kfHasMapPoint.data(), fHasMapPoint ? fHasMapPoint->data() : nullptr,
                               angleKF.data(), angleF.data(), TH_LOW, strictLess ? 1 : 0, mfNNratio, mbCheckOrientation ? 1 : 0,

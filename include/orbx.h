@@ -221,6 +221,15 @@ int orbm_match_groups(orbm_t* h, const uint8_t* q, int nq, const uint8_t* t, int
                       const float* q_angle, const float* t_angle, int th, int strict_lt, float ratio, int check_ori,
                       int* match_t_of_q, int* match_q_of_t);
 
+/* The same overload for a two-camera frame (F.Nleft != -1: a second fisheye camera, src/ORBmatcher.cc:305-333 and 362-389).  The train
+ * features are the frame's left keys [0, t_nleft) followed by its right keys (F.mDescriptors is stacked that way); a query keeps a
+ * best / second-best pair per camera, the right-camera match needs only best <= th (the ratio test is disabled there in the reference)
+ * and is only looked at when the left best is <= th, exactly as the reference nests it, so one query can claim two train features.
+ * match_q_of_t[nt] (= vpMapPointMatches): the query that claimed the train feature, -1 = none.  nt <= 8192.  Returns nmatches. */
+int orbm_match_groups_two_cameras(orbm_t* h, const uint8_t* q, int nq, const uint8_t* t, int nt, int t_nleft, int ngroups, const int* q_off,
+                                  const int* q_idx, const int* t_off, const int* t_idx, const uint8_t* q_valid, const float* q_angle,
+                                  const float* t_angle, int th, float ratio, int check_ori, int* match_q_of_t);
+
 /* Device-resident brute-force form (ngroups == 1, all features valid) for streams whose descriptors never
  * leave the GPU: d_q / d_t are device descriptor arrays, d_q_kp / d_t_kp the device keypoint arrays written
  * by orbx_extract_batch_device (angles are read from them), d_nq / d_nt device ints with the live counts

@@ -279,6 +279,27 @@ def match_groups(q, t, q_angle=None, t_angle=None, th=50, ratio=0.7, strict_lt=F
     return n, mq, mt
 
 
+def match_groups_two_cameras(q, t, t_nleft, q_angle=None, t_angle=None, th=50, ratio=0.7, check_ori=True, groups=None, q_valid=None):
+    """SearchByBoW(KeyFrame*, Frame&) with F.Nleft = t_nleft (see orb_oracle.h).  Returns (nmatches, match_q_of_t)."""
+    q = np.ascontiguousarray(q, np.uint8)
+    t = np.ascontiguousarray(t, np.uint8)
+    nq, nt = len(q), len(t)
+    if groups is None:
+        ng, qo, qi, to, ti = 1, None, None, None, None
+    else:
+        qo, qi, to, ti = (np.ascontiguousarray(a, np.int32) for a in groups)
+        ng = len(qo) - 1
+    qa = _opt(q_angle if q_angle is not None else np.zeros(nq), np.float32)
+    ta = _opt(t_angle if t_angle is not None else np.zeros(nt), np.float32)
+    qv = _opt(q_valid, np.uint8)
+    mt = np.zeros(nt, np.int32)
+    L = lib()
+    L.orao_match_groups_two_cameras.restype = C.c_int
+    L.orao_match_groups_two_cameras.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 7 + [C.c_int, C.c_float, C.c_int, C.c_void_p]
+    n = L.orao_match_groups_two_cameras(_p(q), nq, _p(t), nt, int(t_nleft), ng, _p(qo), _p(qi), _p(to), _p(ti), _p(qv), _p(qa), _p(ta), int(th), float(ratio), int(check_ori), _p(mt))
+    return n, mt
+
+
 def match_window(d1, kp1, d2, kp2, prev_matched, bounds, window=100, th=50, ratio=0.9, check_ori=True):
     d1 = np.ascontiguousarray(d1, np.uint8)
     d2 = np.ascontiguousarray(d2, np.uint8)

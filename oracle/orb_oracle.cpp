@@ -1103,6 +1103,78 @@ int orao_match_groups(const uint8_t* q, int nq, const uint8_t* t, int nt, int ng
   return nmatches;
 }
 
+// SearchByBoW(KeyFrame*, Frame&) with F.Nleft != -1 (src/ORBmatcher.cc:237-421, the two-camera branch :305-333 and :362-389): the
+// train features are the frame's left keys [0, t_nleft) followed by its right keys; every query keeps a best / second-best pair per
+// camera from ONE scan of its group.  The right-camera match is taken whenever its best distance is <= TH_LOW (the ratio test is
+// disabled there: "|| true", :363) -- but only inside the `bestDist1 <= TH_LOW` block of the LEFT camera (:335, :362), as the
+// reference nests it.  Output as the reference's vpMapPointMatches: for every train feature, the query that claimed it.
+int orao_match_groups_two_cameras(const uint8_t* q, int nq, const uint8_t* t, int nt, int t_nleft, int ngroups, const int* q_off,
+                                  const int* q_idx, const int* t_off, const int* t_idx, const uint8_t* q_valid, const float* q_angle,
+                                  const float* t_angle, int th, float ratio, int check_ori, int* match_q_of_t) {
+  std::vector<int> mt(nt, -1);
+  std::vector<int> rotHist[HISTO_LENGTH];
+  int              nmatches = 0;
+  const int        one_q[2] = {0, nq}, one_t[2] = {0, nt};
+  if (ngroups == 1 && !q_off) q_off = one_q;
+  if (ngroups == 1 && !t_off) t_off = one_t;
+  for (int g = 0; g < ngroups; g++) {
+    for (int iq = q_off[g]; iq < q_off[g + 1]; iq++) {
+      const int realIdxKF = q_idx ? q_idx[iq] : iq;
+      if (q_valid && !q_valid[realIdxKF]) continue;  // !pMP || pMP->isBad()
+      const uint8_t* dKF       = q + (size_t)realIdxKF * 32;
+      int            bestDist1 = 256, bestIdxF = -1, bestDist2 = 256;
+      int            bestDist1R = 256, bestIdxFR = -1, bestDist2R = 256;
+      for (int it = t_off[g]; it < t_off[g + 1]; it++) {
+        const int realIdxF = t_idx ? t_idx[it] : it;
+        if (mt[realIdxF] >= 0) continue;
+        const int dist = orao_hamming(dKF, t + (size_t)realIdxF * 32);
+        if (realIdxF < t_nleft && dist < bestDist1) {
+          bestDist2 = bestDist1;
+          bestDist1 = dist;
+          bestIdxF  = realIdxF;
+        } else if (realIdxF < t_nleft && dist < bestDist2) {
+          bestDist2 = dist;
+        }
+        if (realIdxF >= t_nleft && dist < bestDist1R) {
+          bestDist2R = bestDist1R;
+          bestDist1R = dist;
+          bestIdxFR  = realIdxF;
+        } else if (realIdxF >= t_nleft && dist < bestDist2R) {
+          bestDist2R = dist;
+        }
+      }
+      (void)bestDist2R;
+      if (bestDist1 <= th) {
+        if (static_cast<float>(bestDist1) < ratio * static_cast<float>(bestDist2)) {
+          mt[bestIdxF] = realIdxKF;
+          if (check_ori) rotHist[rotBin(q_angle[realIdxKF], t_angle[bestIdxF])].push_back(bestIdxF);
+          nmatches++;
+        }
+        if (bestDist1R <= th) {
+          mt[bestIdxFR] = realIdxKF;
+          if (check_ori) rotHist[rotBin(q_angle[realIdxKF], t_angle[bestIdxFR])].push_back(bestIdxFR);
+          nmatches++;
+        }
+      }
+    }
+  }
+  if (check_ori) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    int counts[HISTO_LENGTH];
+    for (int i = 0; i < HISTO_LENGTH; i++) counts[i] = (int)rotHist[i].size();
+    orao_three_maxima(counts, HISTO_LENGTH, &ind1, &ind2, &ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i == ind1 || i == ind2 || i == ind3) continue;
+      for (size_t j = 0; j < rotHist[i].size(); j++) {
+        mt[rotHist[i][j]] = -1;
+        nmatches--;
+      }
+    }
+  }
+  if (match_q_of_t) memcpy(match_q_of_t, mt.data(), sizeof(int) * nt);
+  return nmatches;
+}
+
 // SearchForInitialization (src/ORBmatcher.cc:666-782) + Frame grid (src/Frame.cc:524-553, 788-877)
 int orao_match_window(const uint8_t* d1, const orao_keypoint_t* kp1, int n1, const uint8_t* d2, const orao_keypoint_t* kp2,
                       int n2, float* prev_matched, float mnMinX, float mnMaxX, float mnMinY, float mnMaxY, int windowSize,

@@ -104,6 +104,12 @@ int orao_match_groups(const uint8_t* q, int nq, const uint8_t* t, int nt, int ng
                       const int* q_idx, const int* t_off, const int* t_idx, const uint8_t* q_valid,
                       const uint8_t* t_valid, const float* q_angle, const float* t_angle, int th, int strict_lt,
                       float ratio, int check_ori, int* match_t_of_q, int* match_q_of_t);
+/* SearchByBoW(KeyFrame*, Frame&) for a two-camera frame (F.Nleft != -1, src/ORBmatcher.cc:305-333, 362-389): train features =
+ * left keys [0, t_nleft) then right keys.  match_q_of_t[nt] = the query that claimed the train feature (vpMapPointMatches), -1 = none. */
+int orao_match_groups_two_cameras(const uint8_t* q, int nq, const uint8_t* t, int nt, int t_nleft, int ngroups, const int* q_off,
+                                  const int* q_idx, const int* t_off, const int* t_idx, const uint8_t* q_valid, const float* q_angle,
+                                  const float* t_angle, int th, float ratio, int check_ori, int* match_q_of_t);
+
 /* ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:666-782) with the Frame grid restated
  * (src/Frame.cc:524-553, 788-877; 64x48 grid over [min_x,max_x]x[min_y,max_y]).
  * kp1/kp2: keypoints (x, y, angle, octave); prev_matched: nq x 2 floats, updated in place

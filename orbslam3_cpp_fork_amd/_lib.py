@@ -71,6 +71,7 @@ SIGNATURES = {
     "orbm_hamming": (_i, [_vp, _vp]),
     "orbm_three_maxima": (None, [_vp, _i, _ip, _ip, _ip]),
     "orbm_match_groups": (_i, [_vp, _vp, _i, _vp, _i, _i] + [_vp] * 8 + [_i, _i, _f, _i, _vp, _vp]),
+    "orbm_match_groups_two_cameras": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _i, _vp]),
     "orbm_match_bruteforce_device": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp, _vp, _vp]),
     "orbm_match_pairs_device": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _f, _i, _vp, _vp, _vp]),
     "orbm_match_pairs_bow_device": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _vp, _vp, _vp]),

@@ -1436,6 +1436,229 @@ static int launch_groups(orbm_matcher* h, GroupArgs& a, int nq_cap, hipStream_t 
   return 0;
 }
 
+}  // extern "C"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// SearchByBoW(KeyFrame*, Frame&) for a two-camera frame (F.Nleft != -1, src/ORBmatcher.cc:305-333 and 362-389).  The train
+// features are the frame's left keys [0, nleft) followed by its right keys; a query keeps a best / second-best pair PER CAMERA
+// from one scan of its group, accepts the left match under the usual tests and the right one whenever its distance is <= th
+// ("|| true", :363) -- inside the left camera's `bestDist1 <= TH_LOW` block, as the reference nests it -- so one query can claim
+// two train features.  Not a headline path (no BASELINE configuration has a second fisheye camera): one wave walks the queries in
+// the reference's order, its lanes share a query's candidates; the group's candidate descriptors and a slice of 64 query
+// descriptors are staged in LDS so that the walk itself touches no global memory, and the claims (vpMapPointMatches) live in LDS.
+// The sequential scan's tie rule (strict `<`: the first of equal distances wins) is kept by reducing on (distance, position).
+// ------------------------------------------------------------------------------------------------
+constexpr int kTwoCamMaxTrain = 8192;  // claims + bins in LDS
+constexpr int kTwoCamStage    = 256;   // candidates of a group held in LDS (larger groups are read from global memory)
+
+struct TwoCamArgs {
+  const uint8_t *q, *t;
+  int            nq, nt, nleft, ngroups;
+  const int *    q_off, *q_idx, *t_off, *t_idx;
+  const uint8_t* q_valid;
+  const float *  q_angle, *t_angle;
+  int            th, check_ori;
+  float          ratio;
+  int *          match_q_of_t, *nmatches;
+};
+
+__global__ __launch_bounds__(64) void k_group_two_cameras(TwoCamArgs a) {
+  __shared__ int      sMt[kTwoCamMaxTrain];
+  __shared__ uint8_t  sBin[kTwoCamMaxTrain];
+  __shared__ uint32_t sT[kTwoCamStage][9];  // 8 words + 1 pad: lanes read different rows, same word
+  __shared__ int      sTi[kTwoCamStage];
+  __shared__ uint32_t sQ[64][9];
+  __shared__ int      sQi[64];
+  __shared__ int      hist[kHistoLen];
+  const int           lane = threadIdx.x;
+  for (int i = lane; i < a.nt; i += 64) sMt[i] = -1, sBin[i] = 0xff;
+  if (lane < kHistoLen) hist[lane] = 0;
+  __syncthreads();
+  int            nmatches = 0;
+  const uint32_t kNone    = (256u << 20) | 0xfffffu;
+  for (int g = 0; g < a.ngroups; g++) {
+    const int q0 = a.q_off ? a.q_off[g] : 0, q1 = a.q_off ? a.q_off[g + 1] : a.nq;
+    const int t0 = a.t_off ? a.t_off[g] : 0, t1 = a.t_off ? a.t_off[g + 1] : a.nt;
+    const int nT = t1 - t0;
+    if (q1 <= q0 || nT <= 0) continue;
+    const bool staged = nT <= kTwoCamStage;
+    if (staged) {
+      for (int p = lane; p < nT; p += 64) {
+        const int       rt = a.t_idx ? a.t_idx[t0 + p] : t0 + p;
+        const uint32_t* d  = reinterpret_cast<const uint32_t*>(a.t + (size_t)rt * 32);
+        sTi[p]             = rt;
+#pragma unroll
+        for (int w = 0; w < 8; w++) sT[p][w] = d[w];
+      }
+    }
+    for (int qb = q0; qb < q1; qb += 64) {
+      __syncthreads();  // the previous slice (and the staged candidates) are no longer / now readable
+      if (qb + lane < q1) {
+        const int       rq = a.q_idx ? a.q_idx[qb + lane] : qb + lane;
+        const uint32_t* d  = reinterpret_cast<const uint32_t*>(a.q + (size_t)rq * 32);
+        sQi[lane]          = (a.q_valid && !a.q_valid[rq]) ? -1 : rq;  // !pMP || pMP->isBad()
+#pragma unroll
+        for (int w = 0; w < 8; w++) sQ[lane][w] = d[w];
+      }
+      __syncthreads();
+      const int nq = min(64, q1 - qb);
+      for (int j = 0; j < nq; j++) {
+        const int rq = sQi[j];  // wave-uniform
+        if (rq < 0) continue;
+        uint32_t qw[8];
+#pragma unroll
+        for (int w = 0; w < 8; w++) qw[w] = sQ[j][w];
+        uint32_t l1 = kNone, l2 = kNone, r1 = kNone, r2 = kNone;  // this lane's two smallest (distance << 20 | position) per camera
+        for (int p = lane; p < nT; p += 64) {
+          int rt, d = 0;
+          if (staged) {
+            rt = sTi[p];
+            if (sMt[rt] >= 0) continue;  // vpMapPointMatches[realIdxF]
+#pragma unroll
+            for (int w = 0; w < 8; w++) d += __popc(qw[w] ^ sT[p][w]);
+          } else {
+            rt = a.t_idx ? a.t_idx[t0 + p] : t0 + p;
+            if (sMt[rt] >= 0) continue;
+            const uint32_t* td = reinterpret_cast<const uint32_t*>(a.t + (size_t)rt * 32);
+#pragma unroll
+            for (int w = 0; w < 8; w++) d += __popc(qw[w] ^ td[w]);
+          }
+          const uint32_t key = ((uint32_t)d << 20) | (uint32_t)p;
+          if (rt < a.nleft) {
+            l2 = min(l2, max(l1, key)), l1 = min(l1, key);
+          } else {
+            r2 = min(r2, max(r1, key)), r1 = min(r1, key);
+          }
+        }
+        // the wave's smallest key per camera, and the smallest of the rest (its distance is bestDist2)
+        const uint32_t L1 = wave_min_u32(l1), L2 = wave_min_u32(l1 == L1 ? l2 : l1);
+        const uint32_t R1 = wave_min_u32(r1);
+        const int      bestDist1 = (int)(L1 >> 20), bestDist2 = (int)(L2 >> 20), bestDist1R = (int)(R1 >> 20);
+        if (bestDist1 <= a.th) {
+          if ((float)bestDist1 < a.ratio * (float)bestDist2) {
+            const int pL = (int)(L1 & 0xfffffu);
+            const int rt = staged ? sTi[pL] : (a.t_idx ? a.t_idx[t0 + pL] : t0 + pL);
+            if (lane == 0) {
+              sMt[rt] = rq;
+              if (a.check_ori) {
+                const int bin = rot_bin(a.q_angle[rq], a.t_angle[rt]);
+                sBin[rt]      = (uint8_t)bin;
+                hist[bin]++;
+              }
+            }
+            nmatches++;
+          }
+          if (bestDist1R <= a.th) {
+            const int pR = (int)(R1 & 0xfffffu);
+            const int rt = staged ? sTi[pR] : (a.t_idx ? a.t_idx[t0 + pR] : t0 + pR);
+            if (lane == 0) {
+              sMt[rt] = rq;
+              if (a.check_ori) {
+                const int bin = rot_bin(a.q_angle[rq], a.t_angle[rt]);
+                sBin[rt]      = (uint8_t)bin;
+                hist[bin]++;
+              }
+            }
+            nmatches++;
+          }
+          __syncthreads();  // the claims are visible to every lane before the next query reads them
+        }
+      }
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  int removed = 0;
+  if (a.check_ori) {
+    int i1, i2, i3;
+    three_maxima(hist, kHistoLen, i1, i2, i3);
+    for (int i = lane; i < a.nt; i += 64) {
+      const int b = sBin[i];
+      if (sMt[i] >= 0 && b != i1 && b != i2 && b != i3) sMt[i] = -1, removed++;
+    }
+    removed = wave_sum_i32(removed);
+  }
+  __syncthreads();
+  for (int i = lane; i < a.nt; i += 64) a.match_q_of_t[i] = sMt[i];
+  if (lane == 0) *a.nmatches = nmatches - removed;
+}
+
+}  // namespace
+
+extern "C" {
+
+int orbm_match_groups_two_cameras(orbm_t* h, const uint8_t* q, int nq, const uint8_t* t, int nt, int t_nleft, int ngroups, const int* q_off,
+                                  const int* q_idx, const int* t_off, const int* t_idx, const uint8_t* q_valid, const float* q_angle,
+                                  const float* t_angle, int th, float ratio, int check_ori, int* match_q_of_t) {
+  if (!h || nq < 0 || nt < 0 || (nq > 0 && !q) || (nt > 0 && !t) || ngroups < 1 || t_nleft < 0 || t_nleft > nt) {
+    set_err("orbm_match_groups_two_cameras: bad arguments");
+    return -2;
+  }
+  const bool grouped = q_idx || t_idx || q_off || t_off;
+  if (grouped && !(q_idx && t_idx && q_off && t_off)) {
+    set_err("orbm_match_groups_two_cameras: q_off, q_idx, t_off, t_idx must be given together");
+    return -2;
+  }
+  if (!grouped && ngroups != 1) {
+    set_err("orbm_match_groups_two_cameras: ngroups > 1 needs the group arrays");
+    return -2;
+  }
+  if (check_ori && (!q_angle || !t_angle)) {
+    set_err("orbm_match_groups_two_cameras: check_ori needs angles");
+    return -2;
+  }
+  if (nt > kTwoCamMaxTrain) {
+    set_err("orbm_match_groups_two_cameras: more than 8192 train features");
+    return -2;
+  }
+  const int nqe = grouped ? q_off[ngroups] : nq, nte = grouped ? t_off[ngroups] : nt;
+  if (grouped) {
+    for (int g = 0; g < ngroups; g++)
+      if (q_off[g] > q_off[g + 1] || t_off[g] > t_off[g + 1] || q_off[g] < 0 || t_off[g] < 0) {
+        set_err("orbm_match_groups_two_cameras: offsets must be non-decreasing");
+        return -2;
+      }
+    for (int i = 0; i < nqe; i++)
+      if (q_idx[i] < 0 || q_idx[i] >= nq) {
+        set_err("orbm_match_groups_two_cameras: q_idx out of range");
+        return -2;
+      }
+    for (int i = 0; i < nte; i++)
+      if (t_idx[i] < 0 || t_idx[i] >= nt) {
+        set_err("orbm_match_groups_two_cameras: t_idx out of range");
+        return -2;
+      }
+  }
+  HIP_TRYM(hipSetDevice(h->device));
+  hipStream_t  s       = h->stream;
+  const size_t inBytes = (size_t)nq * (32 + 4 + 1) + (size_t)nt * (32 + 4) + (size_t)(2 * ngroups + 2 + nqe + nte) * 4 + 16 * 16;
+  if (h->in.reserve(inBytes) || h->out.reserve((size_t)(nt + 4) * 4 + 64)) return -3;
+  TwoCamArgs a;
+  memset(&a, 0, sizeof(a));
+  Arena& in = h->in;
+  a.q = in.put(q, (size_t)nq * 32), a.t = in.put(t, (size_t)nt * 32);
+  a.q_angle = q_angle ? in.put(q_angle, nq) : nullptr, a.t_angle = t_angle ? in.put(t_angle, nt) : nullptr;
+  a.q_valid = q_valid ? in.put(q_valid, nq) : nullptr;
+  if (grouped) {
+    a.q_off = in.put(q_off, ngroups + 1), a.t_off = in.put(t_off, ngroups + 1);
+    a.q_idx = in.put(q_idx, nqe), a.t_idx = in.put(t_idx, nte);
+  }
+  if (!in.ok()) return -3;
+  if (in.off) HIP_TRYM(hipMemcpyAsync(in.d, in.h, in.off, hipMemcpyHostToDevice, s));
+  Arena& out = h->out;
+  a.nmatches = out.put((const int*)nullptr, 4), a.match_q_of_t = out.put((const int*)nullptr, nt);
+  if (!out.ok()) return -3;
+  a.nq = nq, a.nt = nt, a.nleft = t_nleft, a.ngroups = ngroups, a.th = th, a.check_ori = check_ori, a.ratio = ratio;
+  hipLaunchKernelGGL(k_group_two_cameras, dim3(1), dim3(64), 0, s, a);
+  HIP_TRYM(hipGetLastError());
+  HIP_TRYM(hipMemcpyAsync(out.h, out.d, out.off, hipMemcpyDeviceToHost, s));
+  HIP_TRYM(hipStreamSynchronize(s));
+  if (match_q_of_t && nt) memcpy(match_q_of_t, out.host_of(a.match_q_of_t), (size_t)nt * 4);
+  return *out.host_of(a.nmatches);
+}
+
 int orbm_match_groups(orbm_t* h, const uint8_t* q, int nq, const uint8_t* t, int nt, int ngroups, const int* q_off, const int* q_idx,
                       const int* t_off, const int* t_idx, const uint8_t* q_valid, const uint8_t* t_valid, const float* q_angle,
                       const float* t_angle, int th, int strict_lt, float ratio, int check_ori, int* match_t_of_q, int* match_q_of_t) {

@@ -86,10 +86,31 @@ class ORBmatcher:
         )
         return n, mq, mt
 
-    def SearchByBoW(self, kf_desc, kf_angle, kf_featvec, kf_has_mappoint, f_desc, f_angle, f_featvec):
-        """SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches) (src/ORBmatcher.cc:237-421, F.Nleft == -1).
+    def SearchByBoW(self, kf_desc, kf_angle, kf_featvec, kf_has_mappoint, f_desc, f_angle, f_featvec, f_nleft=-1):
+        """SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches) (src/ORBmatcher.cc:237-421).  f_nleft = F.Nleft: -1 for a one-camera
+        frame; else f_desc / f_angle hold the left keys [0, Nleft) followed by the right keys and the two-camera branch
+        (:305-333, 362-389) runs, where one KeyFrame feature may hand its MapPoint to a left AND a right Frame feature.
         Returns (nmatches, match_kf_of_f[F.N]) -- the KeyFrame feature whose MapPoint each Frame feature received, -1 = NULL."""
         groups = None if kf_featvec is None else flatten_feature_vectors(kf_featvec, f_featvec)
+        if f_nleft != -1:
+            q = np.ascontiguousarray(kf_desc, np.uint8).reshape(-1, 32)
+            t = np.ascontiguousarray(f_desc, np.uint8).reshape(-1, 32)
+            nq, nt = len(q), len(t)
+            qa = np.ascontiguousarray(kf_angle if kf_angle is not None else np.zeros(nq), np.float32)
+            ta = np.ascontiguousarray(f_angle if f_angle is not None else np.zeros(nt), np.float32)
+            qv = None if kf_has_mappoint is None else np.ascontiguousarray(kf_has_mappoint, np.uint8)
+            if groups is None:
+                ng, qo, qi, to, ti = 1, None, None, None, None
+            else:
+                qo, qi, to, ti = (np.ascontiguousarray(a, np.int32) for a in groups)
+                ng = len(qo) - 1
+                if ng == 0:
+                    return 0, np.full(nt, -1, np.int32)
+            mt = np.zeros(nt, np.int32)
+            n = check(_lib.lib().orbm_match_groups_two_cameras(self._h, ptr(q), nq, ptr(t), nt, int(f_nleft), ng, ptr(qo), ptr(qi), ptr(to), ptr(ti), ptr(qv),
+                                                               ptr(qa), ptr(ta), self.TH_LOW, self.mfNNratio, int(self.mbCheckOrientation), ptr(mt)),
+                      "orbm_match_groups_two_cameras")
+            return n, mt
         n, mq, mt = self._groups(kf_desc, f_desc, kf_angle, f_angle, groups, kf_has_mappoint, None, self.TH_LOW, False)
         return n, mt
 

@@ -498,3 +498,52 @@ def test_search_for_triangulation(oracle):
     e = (np.zeros(1, np.int32), np.zeros(0, np.int32), np.zeros(1, np.int32), np.zeros(0, np.int32))
     n, pairs = ORBmatcher(0.6, True).SearchForTriangulation(kA, dA, None, e, kB, dB, None, None, F, ep, oex_sf, oex_sf)
     assert n == 0 and len(pairs) == 0
+
+
+@pytest.mark.parametrize("ori", [True, False])
+def test_search_by_bow_two_cameras(oracle, synth, ori):
+    """SearchByBoW(KeyFrame*, Frame&) with F.Nleft != -1 (src/ORBmatcher.cc:305-333, 362-389): left keys then right keys in the train
+    set, a best / second pair per camera, the right match without ratio test and only under the left camera's `<= TH_LOW` block.
+    Cases: planted left + right copies of the same KeyFrame descriptor (one query claims two rows), queries without a left
+    candidate (their right match must NOT be taken), duplicate descriptors (the first of equal distances wins), a group larger
+    than the kernel's LDS stage (read from global memory), brute force."""
+    rng = np.random.default_rng(7)
+    from orbslam3_cpp_fork_amd.matcher import flatten_feature_vectors
+
+    nq, nleft, nright = 900, 700, 600
+    kf = synth.random_descriptors(nq, 11)
+    left = synth.planted_descriptors(kf[rng.permutation(nq)[:nleft]], 12, max_flips=45)
+    right = synth.planted_descriptors(kf[rng.permutation(nq)[:nright]], 13, max_flips=45)
+    right[:40] = right[40:80]  # duplicates: ties on distance
+    t = np.concatenate([left, right])
+    nt = len(t)
+    nodes = 60
+    fq, ft = {}, {}
+    # descriptors of one KeyFrame feature and of its planted copies share a node most of the time (as a vocabulary would put them)
+    node_of_q = rng.integers(0, nodes, nq)
+    for i in range(nq):
+        fq.setdefault(int(node_of_q[i]), []).append(i)
+    d = np.unpackbits(t[:, None, :] ^ kf[None, :, :], axis=2).sum(2) if nt * nq < 2_000_000 else None
+    near = d.argmin(1)
+    for i in range(nt):
+        n = int(node_of_q[near[i]]) if rng.uniform() < 0.85 else int(rng.integers(0, nodes))
+        ft.setdefault(n, []).append(i)
+    ft.pop(5, None)
+    # one node keeps only right-camera features: its queries have no left candidate
+    ft[7] = [i for i in ft.get(7, []) if i >= nleft]
+    groups = flatten_feature_vectors(fq, ft)
+    qv = (rng.uniform(size=nq) < 0.85).astype(np.uint8)
+    qa = rng.choice([0.0, 14.9, 15.0, 100.0, 344.9, 345.0, 359.0], nq).astype(np.float32)
+    ta = np.zeros(nt, np.float32)
+    m = _mk(0.8, ori)
+    n0, mt0 = oracle.match_groups_two_cameras(kf, t, nleft, qa, ta, th=50, ratio=0.8, check_ori=ori, groups=groups, q_valid=qv)
+    n1, mt1 = m.SearchByBoW(kf, qa, fq, qv, t, ta, ft, f_nleft=nleft)
+    assert n0 == n1 and (mt0 == mt1).all()
+    claimed = mt0[mt0 >= 0]
+    assert n0 > 300 and len(claimed) > len(np.unique(claimed))  # some queries did claim a left and a right feature
+    # brute force (one group of 1300 candidates: larger than the LDS stage), and a single-camera-sized Nleft edge (everything left)
+    for nl in (nleft, nt, 0):
+        n0, mt0 = oracle.match_groups_two_cameras(kf, t, nl, qa, ta, th=50, ratio=0.8, check_ori=ori, q_valid=qv)
+        n1, mt1 = m.SearchByBoW(kf, qa, None, qv, t, ta, None, f_nleft=nl)
+        assert n0 == n1 and (mt0 == mt1).all()
+    m.close()
