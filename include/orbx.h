@@ -306,6 +306,21 @@ int orbm_search_by_projection_map(orbm_t* h, const uint8_t* mp_desc, const float
                                   const float* scale_factors, int nlevels, float ratio, float min_x, float max_x, float min_y, float max_y,
                                   int th_dist, int* cur_of_mp, int* mp_of_cur);
 
+/* The same search for a two-camera frame (F.Nleft != -1; src/ORBmatcher.cc:139-146 and 152-226).  cur_desc / cur_kp hold the left keys
+ * [0, nleft) followed by the right keys (mvKeys, mvKeysRight), cur_occupied likewise; the two grids of Frame::AssignFeaturesToGrid are
+ * built from them.  Per map point: valid_l = mbTrackInView, valid_r = mbTrackInViewR && mnTrackScaleLevelR != -1 (both 0 for the points
+ * the loop head skips, :50-62); uv_l / level_l / radius_l = (mTrackProjX, mTrackProjY), mnTrackScaleLevel, RadiusByViewingCos(mTrackViewCos)
+ * (* th when th != 1); uv_r / level_r / radius_r = the ...R members, the radius without the factor (:158).  An accepted left match also
+ * hands the point to left_to_right[best] + nleft (mvLeftToRightMatch, -1 = none), an accepted right match to right_to_left[best]; a
+ * ratio veto in the left block skips the point's right search, as the reference's `continue` does.  mp_of_cur[n] = F.mvpMapPoints after
+ * the call (map point index, -1 = untouched).  n <= 16384.  Returns nmatches (every assignment counts, as in the reference). */
+int orbm_search_by_projection_map_two_cameras(orbm_t* h, const uint8_t* mp_desc, int n1, const float* uv_l, const int* level_l, const float* radius_l,
+                                              const uint8_t* valid_l, const float* uv_r, const int* level_r, const float* radius_r,
+                                              const uint8_t* valid_r, const uint8_t* cur_desc, const orbx_keypoint_t* cur_kp, int n, int nleft,
+                                              const uint8_t* cur_occupied, const int* left_to_right, const int* right_to_left,
+                                              const float* scale_factors, int nlevels, float ratio, float min_x, float max_x, float min_y, float max_y,
+                                              int th_dist, int* mp_of_cur);
+
 /* The windowed best-candidate search of the remaining projection matchers, on arrays:
  *   ORBmatcher::SearchByProjection(KeyFrame*, Sophus::Sim3f&, vpPoints, vpMatched, th, ratioHamming) (src/ORBmatcher.cc:423-538; :540-664
  *     is the same search) -- claim = 1, t_occupied[idx] = (vpMatched[idx] != NULL), th_dist = floor(TH_LOW * ratioHamming);

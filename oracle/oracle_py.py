@@ -322,6 +322,28 @@ def stereo_matches(ex_left, ex_right, kl, dl, kr, dr, mb, mbf):
     return n, u, d
 
 
+def search_by_projection_map_two_cameras(mp_desc, left, right, cur_desc, cur_kp, nleft, scale_factors, ratio, bounds, th_dist=100, cur_occupied=None,
+                                         left_to_right=None, right_to_left=None):
+    """SearchByProjection(F, vpMapPoints, ...) with F.Nleft = nleft (orb_oracle.h).  left / right = (uv, level, radius, valid).  -> (n, mp_of_cur)."""
+    d1 = np.ascontiguousarray(mp_desc, np.uint8)
+    d2 = np.ascontiguousarray(cur_desc, np.uint8)
+    kp = np.ascontiguousarray(cur_kp, KP_DTYPE)
+    cams = []
+    for uv, lv, rad, va in (left, right):
+        cams.append((np.ascontiguousarray(uv, np.float32).reshape(-1, 2), np.ascontiguousarray(lv, np.int32), np.ascontiguousarray(rad, np.float32),
+                     np.ascontiguousarray(va, np.uint8)))
+    occ, l2r, r2l = _opt(cur_occupied, np.uint8), _opt(left_to_right, np.int32), _opt(right_to_left, np.int32)
+    sf = np.ascontiguousarray(scale_factors, np.float32)
+    out = np.zeros(len(d2), np.int32)
+    L = lib()
+    L.orao_search_by_projection_map_two_cameras.restype = C.c_int
+    L.orao_search_by_projection_map_two_cameras.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 10 + [C.c_int, C.c_int] + [C.c_void_p] * 4 + [C.c_float] * 5 + [C.c_int, C.c_void_p]
+    (u0, l0, r0, v0), (u1, l1, r1, v1) = cams
+    n = L.orao_search_by_projection_map_two_cameras(_p(d1), len(d1), _p(u0), _p(l0), _p(r0), _p(v0), _p(u1), _p(l1), _p(r1), _p(v1), _p(d2), _p(kp), len(d2), int(nleft),
+                                                    _p(occ), _p(l2r), _p(r2l), _p(sf), float(ratio), *[float(b) for b in bounds], int(th_dist), _p(out))
+    return n, out
+
+
 def search_by_projection(last_desc, last_uv, last_invz, last_octave, last_angle, last_valid, cur_desc, cur_kp, cur_u_right, cur_occupied,
                          scale_factors, th, direction, mbf, bounds, th_dist=100, check_ori=True):
     """ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) at array level (see orb_oracle.h)."""

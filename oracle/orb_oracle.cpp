@@ -1361,6 +1361,124 @@ int orao_search_by_projection_map(const uint8_t* mp_desc, const float* mp_uv, co
   return nmatches;
 }
 
+// SearchByProjection(Frame& F, const std::vector<MapPoint*>& vpMapPoints, th, bFarPoints, thFarPoints) for a two-camera frame
+// (F.Nleft != -1, src/ORBmatcher.cc:38-227 with the branches :139-146 and :152-226).  cur_desc / cur_kp hold the left keys
+// [0, nleft) followed by the right keys (mvKeys, mvKeysRight); the two grids are Frame::mGrid / mGridRight (src/Frame.cc:524-553).
+// valid_l[i] = mbTrackInView, valid_r[i] = mbTrackInViewR && mnTrackScaleLevelR != -1, both already cleared for the points the
+// loop head skips (:50-62); radius_l = RadiusByViewingCos(mTrackViewCos) (* th when th != 1), radius_r =
+// RadiusByViewingCos(mTrackViewCosR) (no factor, :158).  A `continue` of the left block (:138-140) skips the point's right search
+// too, as in the reference.  mp_of_cur[n] = F.mvpMapPoints after the call (index of the map point, -1 = untouched).
+int orao_search_by_projection_map_two_cameras(const uint8_t* mp_desc, int n1, const float* uv_l, const int* level_l, const float* radius_l,
+                                              const uint8_t* valid_l, const float* uv_r, const int* level_r, const float* radius_r,
+                                              const uint8_t* valid_r, const uint8_t* cur_desc, const orao_keypoint_t* cur_kp, int n, int nleft,
+                                              const uint8_t* cur_occupied, const int* left_to_right, const int* right_to_left,
+                                              const float* mvScaleFactors, float mfNNratio, float mnMinX, float mnMaxX, float mnMinY,
+                                              float mnMaxY, int th_dist, int* mp_of_cur) {
+  const int   GRID_COLS = 64, GRID_ROWS = 48;
+  const float gwInv = static_cast<float>(GRID_COLS) / (mnMaxX - mnMinX);
+  const float ghInv = static_cast<float>(GRID_ROWS) / (mnMaxY - mnMinY);
+  std::vector<std::vector<int>> grid((size_t)GRID_COLS * GRID_ROWS), gridRight((size_t)GRID_COLS * GRID_ROWS);
+  for (int i = 0; i < n; i++) {  // AssignFeaturesToGrid
+    int posX = (int)std::round((cur_kp[i].x - mnMinX) * gwInv);
+    int posY = (int)std::round((cur_kp[i].y - mnMinY) * ghInv);
+    if (posX < 0 || posX >= GRID_COLS || posY < 0 || posY >= GRID_ROWS) continue;
+    if (i < nleft)
+      grid[(size_t)posX * GRID_ROWS + posY].push_back(i);
+    else
+      gridRight[(size_t)posX * GRID_ROWS + posY].push_back(i - nleft);
+  }
+  std::vector<int> mvpMapPoints(n, -1);
+  auto occupied = [&](int idx) { return mvpMapPoints[idx] >= 0 || (cur_occupied && cur_occupied[idx]); };  // F.mvpMapPoints[idx] with observations
+  auto area     = [&](float x, float y, float rr, int minLevel, int maxLevel, bool bRight, std::vector<int>& vIndices) {
+    vIndices.clear();
+    const int nMinCellX = std::max(0, (int)std::floor((x - mnMinX - rr) * gwInv));
+    if (nMinCellX >= GRID_COLS) return;
+    const int nMaxCellX = std::min(GRID_COLS - 1, (int)std::ceil((x - mnMinX + rr) * gwInv));
+    if (nMaxCellX < 0) return;
+    const int nMinCellY = std::max(0, (int)std::floor((y - mnMinY - rr) * ghInv));
+    if (nMinCellY >= GRID_ROWS) return;
+    const int nMaxCellY = std::min(GRID_ROWS - 1, (int)std::ceil((y - mnMinY + rr) * ghInv));
+    if (nMaxCellY < 0) return;
+    const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+    for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
+      for (int iy = nMinCellY; iy <= nMaxCellY; iy++) {
+        const std::vector<int>& vCell = (!bRight) ? grid[(size_t)ix * GRID_ROWS + iy] : gridRight[(size_t)ix * GRID_ROWS + iy];
+        for (size_t j = 0; j < vCell.size(); j++) {
+          const orao_keypoint_t& kpUn = (!bRight) ? cur_kp[vCell[j]] : cur_kp[nleft + vCell[j]];
+          if (bCheckLevels) {
+            if (kpUn.octave < minLevel) continue;
+            if (maxLevel >= 0 && kpUn.octave > maxLevel) continue;
+          }
+          const float distx = kpUn.x - x, disty = kpUn.y - y;
+          if (std::fabs(distx) < rr && std::fabs(disty) < rr) vIndices.push_back(vCell[j]);
+        }
+      }
+  };
+  int              nmatches = 0;
+  std::vector<int> vIndices;
+  for (int iMP = 0; iMP < n1; iMP++) {
+    const bool inView = valid_l && valid_l[iMP], inViewR = valid_r && valid_r[iMP];
+    if (!inView && !inViewR) continue;
+    const uint8_t* MPdescriptor = mp_desc + (size_t)iMP * 32;
+    bool           skipRight    = false;
+    if (inView) {
+      const int nPredictedLevel = level_l[iMP];
+      area(uv_l[2 * iMP], uv_l[2 * iMP + 1], radius_l[iMP] * mvScaleFactors[nPredictedLevel], nPredictedLevel - 1, nPredictedLevel, false, vIndices);
+      if (!vIndices.empty()) {
+        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+        for (int idx : vIndices) {
+          if (occupied(idx)) continue;
+          const int dist = orao_hamming(MPdescriptor, cur_desc + (size_t)idx * 32);
+          if (dist < bestDist) {
+            bestDist2 = bestDist, bestDist = dist, bestLevel2 = bestLevel, bestLevel = cur_kp[idx].octave, bestIdx = idx;
+          } else if (dist < bestDist2) {
+            bestLevel2 = cur_kp[idx].octave, bestDist2 = dist;
+          }
+        }
+        if (bestDist <= th_dist) {
+          if (bestLevel == bestLevel2 && bestDist > mfNNratio * bestDist2) {
+            skipRight = true;  // `continue` of the loop over map points (:138-140)
+          } else if (bestLevel != bestLevel2 || bestDist <= mfNNratio * bestDist2) {
+            mvpMapPoints[bestIdx] = iMP;
+            if (left_to_right && left_to_right[bestIdx] != -1) {  // :145-149
+              mvpMapPoints[left_to_right[bestIdx] + nleft] = iMP;
+              nmatches++;
+            }
+            nmatches++;
+          }
+        }
+      }
+    }
+    if (skipRight || !inViewR) continue;
+    {
+      const int nPredictedLevel = level_r[iMP];
+      area(uv_r[2 * iMP], uv_r[2 * iMP + 1], radius_r[iMP] * mvScaleFactors[nPredictedLevel], nPredictedLevel - 1, nPredictedLevel, true, vIndices);
+      if (vIndices.empty()) continue;
+      int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+      for (int idx : vIndices) {
+        if (occupied(idx + nleft)) continue;
+        const int dist = orao_hamming(MPdescriptor, cur_desc + (size_t)(idx + nleft) * 32);
+        if (dist < bestDist) {
+          bestDist2 = bestDist, bestDist = dist, bestLevel2 = bestLevel, bestLevel = cur_kp[nleft + idx].octave, bestIdx = idx;
+        } else if (dist < bestDist2) {
+          bestLevel2 = cur_kp[nleft + idx].octave, bestDist2 = dist;
+        }
+      }
+      if (bestDist <= th_dist) {
+        if (bestLevel == bestLevel2 && bestDist > mfNNratio * bestDist2) continue;
+        if (right_to_left && right_to_left[bestIdx] != -1) {  // :214-218
+          mvpMapPoints[right_to_left[bestIdx]] = iMP;
+          nmatches++;
+        }
+        mvpMapPoints[bestIdx + nleft] = iMP;
+        nmatches++;
+      }
+    }
+  }
+  if (mp_of_cur) memcpy(mp_of_cur, mvpMapPoints.data(), sizeof(int) * n);
+  return nmatches;
+}
+
 // cv::undistortPoints for one CV_32FC2 point (OpenCV >= 4.5 undistort.dispatch.cpp, cvUndistortPointsInternal), criteria =
 // TermCriteria(MAX_ITER, 5, 0.01), R empty, P = the 3x3 new camera matrix.
 static void cv_undistort_point(const double A[3][3], const double k[14], const double PP[3][3], float sx, float sy, float* dx, float* dy) {

@@ -143,6 +143,15 @@ int orao_search_by_projection_map(const uint8_t* mp_desc, const float* mp_uv, co
                                   const orao_keypoint_t* cur_kp, const float* cur_u_right, const uint8_t* cur_occupied, int n2,
                                   const float* scale_factors, float ratio, float min_x, float max_x, float min_y, float max_y, int th_dist,
                                   int* cur_of_mp, int* mp_of_cur);
+/* The same search for a two-camera frame (F.Nleft != -1, src/ORBmatcher.cc:139-146, 152-226); see orb_oracle.cpp for the argument
+ * conventions.  mp_of_cur[n]: F.mvpMapPoints after the call. */
+int orao_search_by_projection_map_two_cameras(const uint8_t* mp_desc, int n1, const float* uv_l, const int* level_l, const float* radius_l,
+                                              const uint8_t* valid_l, const float* uv_r, const int* level_r, const float* radius_r,
+                                              const uint8_t* valid_r, const uint8_t* cur_desc, const orao_keypoint_t* cur_kp, int n, int nleft,
+                                              const uint8_t* cur_occupied, const int* left_to_right, const int* right_to_left,
+                                              const float* mvScaleFactors, float mfNNratio, float mnMinX, float mnMaxX, float mnMinY,
+                                              float mnMaxY, int th_dist, int* mp_of_cur);
+
 
 /* The windowed best-candidate search shared by SearchByProjection(KeyFrame*, Sim3f&, ...) (src/ORBmatcher.cc:423-538, :540-664),
  * Fuse (:1149-1328, :1330-1452) and the two directions of SearchBySim3 (:1499-1658): KeyFrame::GetFeaturesInArea

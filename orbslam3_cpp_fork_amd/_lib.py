@@ -79,6 +79,7 @@ SIGNATURES = {
     "orbm_match_window": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _f, _f, _f, _f, _i, _i, _f, _i, _vp]),
     "orbm_search_by_projection": (_i, [_vp] * 7 + [_i] + [_vp] * 4 + [_i, _vp, _i, _f, _i, _f, _f, _f, _f, _f, _i, _i, _vp, _vp]),
     "orbm_search_by_projection_map": (_i, [_vp] * 7 + [_i] + [_vp] * 4 + [_i, _vp, _i, _f, _f, _f, _f, _f, _i, _vp, _vp]),
+    "orbm_search_by_projection_map_two_cameras": (_i, [_vp, _vp, _i] + [_vp] * 10 + [_i, _i] + [_vp] * 4 + [_i, _f, _f, _f, _f, _f, _i, _vp]),
     "orbm_search_in_windows": (_i, [_vp] * 6 + [_i] + [_vp] * 4 + [_i, _vp, _vp, _i, _f, _i, _f, _f, _f, _f, _i, _vp]),
     "orbm_search_for_triangulation": (_i, [_vp] * 5 + [_i] + [_vp] * 4 + [_i, _i] + [_vp] * 8 + [_i] * 5 + [_vp]),
     "orbm_assign_features_to_grid_device": (_i, [_vp, _vp, _vp, _i, _i, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp]),

@@ -2024,6 +2024,261 @@ static int proj_single(orbm_t* h, int mode, const float* inv_sigma2, const float
   return nm;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// SearchByProjection(Frame&, vector<MapPoint*>&, th, ...) for a two-camera frame (F.Nleft != -1, src/ORBmatcher.cc:139-146 and
+// 152-226).  Every map point searches the left grid and then the right grid; an accepted left match also hands the point to the
+// stereo partner mvLeftToRightMatch[best] + Nleft, an accepted right match to mvRightToLeftMatch[best]; a ratio veto in the left
+// block (`continue`, :138-140) skips the point's right search.  The two window searches per point are independent of the claims, so
+// their sorted candidate lists come from the parallel top-K pass of the one-camera form (k_proj_topk, mode 1, once per camera);
+// one wave then walks the points in order with the occupancy of all N features in LDS, reading 64 points' lists at a time.
+// ---------------------------------------------------------------------------------------------------------------
+}  // extern "C"
+
+namespace {
+
+struct MapTwoCamArgs {
+  ProjArgs   L, R;  // per-camera view (mode 1): R.d2 / R.kp2 / R.occupied start at the first right feature
+  int        nleft, n;
+  const int *l2r, *r2l;
+  int *      mp_of_cur, *nmatches;
+};
+
+constexpr uint32_t kTcEmpty = 0xffffffffu;  // list entry: distance << 20 | level << 14 | feature (camera-relative)
+
+// Best and second-best free candidate of one camera for point i, exactly: from the staged list when it decides, else by an exact
+// rescan of the window with the occupancy filter.  Returns e1 / e2 (kTcEmpty = none).
+__device__ __forceinline__ void tc_pick(const ProjArgs& a, int i, const uint32_t* list, int nv, const uint8_t* occ, int occBase, uint32_t& e1, uint32_t& e2) {
+  const int      lane = threadIdx.x & 63;
+  const uint32_t e    = lane < kTopK ? list[lane] : kTcEmpty;
+  const bool     free_ = e != kTcEmpty && !occ[occBase + (int)(e & 0x3fffu)];
+  const unsigned long long fm = __ballot(free_), em = __ballot(e != kTcEmpty);
+  const int      len = __popcll(em);
+  const bool     truncated = nv > len;
+  const int      j1 = fm ? __ffsll((long long)fm) - 1 : -1;
+  const unsigned long long fm2 = j1 >= 0 ? fm & (fm - 1) : 0ull;
+  const int      j2 = fm2 ? __ffsll((long long)fm2) - 1 : -1;
+  e1 = j1 >= 0 ? (uint32_t)__builtin_amdgcn_readlane((int)e, j1) : kTcEmpty;
+  e2 = j2 >= 0 ? (uint32_t)__builtin_amdgcn_readlane((int)e, j2) : kTcEmpty;
+  bool need = false;
+  if (truncated) {
+    if (j1 < 0)
+      need = true;  // everything listed is taken, more candidates exist
+    else if (j2 < 0) {
+      // one free candidate; the runner-up is somewhere beyond the list, at distance >= dK: it matters only if it could veto
+      const int d1 = (int)(e1 >> 20), dK = (int)((uint32_t)__builtin_amdgcn_readlane((int)e, len - 1) >> 20);
+      need         = d1 <= a.thDist && (float)d1 > a.ratio * (float)dK;
+    }
+  }
+  if (!need) return;
+  const ProjQuery q  = proj_query(a, i);
+  const ProjArgs& ar = a;
+  uint32_t        out[kTopK];
+  int             nv2;
+  wave_topk(
+      a.d1 + (size_t)i * 32, a.d2, 0, a.ng,
+      [&ar, &q, occ, occBase](int pos) {
+        const int i2 = proj_candidate(ar, q, pos);
+        return (i2 >= 0 && occ[occBase + i2]) ? -1 : i2;
+      },
+      [thd = ar.dstar - 1](int, int d) { return d <= thd; }, out, &nv2);
+  auto conv = [&](uint32_t key) -> uint32_t {
+    if (key == kEmpty) return kTcEmpty;
+    const int f = a.g_idx[key & kPosMask];
+    return ((key >> kPosBits) << 20) | ((uint32_t)(a.kp2[f].octave & 63) << 14) | (uint32_t)f;
+  };
+  e1 = conv(out[0]), e2 = conv(out[1]);
+}
+
+__global__ __launch_bounds__(64) void k_map_two_cam_resolve(MapTwoCamArgs a) {
+  __shared__ uint8_t  occ[kMaxTrainW];
+  __shared__ uint32_t sList[64][2][kTopK];
+  __shared__ int      sNv[64][2];
+  const int           lane = threadIdx.x, nright = a.n - a.nleft;
+  for (int i = lane; i < a.nleft; i += 64) occ[i] = a.L.occupied ? a.L.occupied[i] : 0;
+  for (int i = lane; i < nright; i += 64) occ[a.nleft + i] = a.R.occupied ? a.R.occupied[i] : 0;
+  for (int i = lane; i < a.n; i += 64) a.mp_of_cur[i] = -1;
+  __syncthreads();
+  int nmatches = 0;
+  for (int c0 = 0; c0 < a.L.n1; c0 += 64) {
+    {  // this lane's point: both lists, converted to (distance, level, feature); -1 in sNv = the camera does not see the point
+      const int i = c0 + lane;
+#pragma unroll
+      for (int cam = 0; cam < 2; cam++) {
+        const ProjArgs& v  = cam ? a.R : a.L;
+        const bool      on = i < v.n1 && v.valid1 && v.valid1[i];
+        sNv[lane][cam]     = on ? v.nvalid[i] : -1;
+#pragma unroll
+        for (int j = 0; j < kTopK; j++) {
+          uint32_t e = kTcEmpty;
+          if (on) {
+            const uint32_t key = v.topk[(size_t)i * kTopK + j];
+            if (key != kEmpty) {
+              const int f = v.g_idx[key & kPosMask];
+              e           = ((key >> kPosBits) << 20) | ((uint32_t)(v.kp2[f].octave & 63) << 14) | (uint32_t)f;
+            }
+          }
+          sList[lane][cam][j] = e;
+        }
+      }
+    }
+    __syncthreads();
+    const int np = min(64, a.L.n1 - c0);
+    for (int j = 0; j < np; j++) {
+      const int i = c0 + j;
+      const int nvL = sNv[j][0], nvR = sNv[j][1];
+      if (nvL < 0 && nvR < 0) continue;  // :50-62
+      bool skipRight = false;
+      if (nvL >= 0) {
+        uint32_t e1, e2;
+        tc_pick(a.L, i, sList[j][0], nvL, occ, 0, e1, e2);
+        if (e1 != kTcEmpty) {
+          const int d1 = (int)(e1 >> 20), l1 = (int)((e1 >> 14) & 63), f1 = (int)(e1 & 0x3fffu);
+          if (d1 <= a.L.thDist) {  // :137
+            const bool veto = e2 != kTcEmpty && l1 == (int)((e2 >> 14) & 63) && (float)d1 > a.L.ratio * (float)(int)(e2 >> 20);
+            if (veto) {
+              skipRight = true;  // `continue` over the map points (:138-140)
+            } else {
+              const int partner = a.l2r ? a.l2r[f1] : -1;
+              if (lane == 0) {
+                occ[f1] = 1, a.mp_of_cur[f1] = i;
+                if (partner != -1) occ[a.nleft + partner] = 1, a.mp_of_cur[a.nleft + partner] = i;  // :145-149
+              }
+              nmatches += partner != -1 ? 2 : 1;
+              __syncthreads();
+            }
+          }
+        }
+      }
+      if (skipRight || nvR < 0) continue;
+      uint32_t e1, e2;
+      tc_pick(a.R, i, sList[j][1], nvR, occ, a.nleft, e1, e2);
+      if (e1 == kTcEmpty) continue;
+      const int d1 = (int)(e1 >> 20), l1 = (int)((e1 >> 14) & 63), f1 = (int)(e1 & 0x3fffu);
+      if (d1 > a.R.thDist) continue;
+      if (e2 != kTcEmpty && l1 == (int)((e2 >> 14) & 63) && (float)d1 > a.R.ratio * (float)(int)(e2 >> 20)) continue;  // :209-211
+      const int partner = a.r2l ? a.r2l[f1] : -1;
+      if (lane == 0) {
+        if (partner != -1) occ[partner] = 1, a.mp_of_cur[partner] = i;  // :214-218
+        occ[a.nleft + f1] = 1, a.mp_of_cur[a.nleft + f1] = i;
+      }
+      nmatches += partner != -1 ? 2 : 1;
+      __syncthreads();
+    }
+    __syncthreads();
+  }
+  if (lane == 0) *a.nmatches = nmatches;
+}
+
+}  // namespace
+
+extern "C" {
+
+int orbm_search_by_projection_map_two_cameras(orbm_t* h, const uint8_t* mp_desc, int n1, const float* uv_l, const int* level_l, const float* radius_l,
+                                              const uint8_t* valid_l, const float* uv_r, const int* level_r, const float* radius_r,
+                                              const uint8_t* valid_r, const uint8_t* cur_desc, const orbx_keypoint_t* cur_kp, int n, int nleft,
+                                              const uint8_t* cur_occupied, const int* left_to_right, const int* right_to_left,
+                                              const float* scale_factors, int nlevels, float ratio, float min_x, float max_x, float min_y, float max_y,
+                                              int th_dist, int* mp_of_cur) {
+  if (!h || n1 < 0 || n < 0 || nleft < 0 || nleft > n || !mp_of_cur || (n1 > 0 && (!mp_desc || !uv_l || !level_l || !radius_l || !valid_l || !uv_r || !level_r ||
+      !radius_r || !valid_r)) || (n > 0 && (!cur_desc || !cur_kp)) || !scale_factors || nlevels < 1 || nlevels > 64 || !(max_x > min_x) || !(max_y > min_y)) {
+    set_err("orbm_search_by_projection_map_two_cameras: bad arguments");
+    return -2;
+  }
+  if (n > kMaxTrainW) {
+    set_err("orbm_search_by_projection_map_two_cameras: more than 16384 frame features");
+    return -2;
+  }
+  const int nright = n - nleft;
+  for (int i = 0; i < n1; i++)
+    if ((valid_l[i] && (level_l[i] < 0 || level_l[i] >= nlevels)) || (valid_r[i] && (level_r[i] < 0 || level_r[i] >= nlevels))) {
+      set_err("orbm_search_by_projection_map_two_cameras: predicted level outside the scale table");
+      return -2;
+    }
+  for (int i = 0; i < nleft; i++)
+    if (left_to_right && (left_to_right[i] < -1 || left_to_right[i] >= nright)) {
+      set_err("orbm_search_by_projection_map_two_cameras: left_to_right out of range");
+      return -2;
+    }
+  for (int i = 0; i < nright; i++)
+    if (right_to_left && (right_to_left[i] < -1 || right_to_left[i] >= nleft)) {
+      set_err("orbm_search_by_projection_map_two_cameras: right_to_left out of range");
+      return -2;
+    }
+  HIP_TRYM(hipSetDevice(h->device));
+  // Frame::AssignFeaturesToGrid for the two grids (src/Frame.cc:524-553): one scan-ordered list per camera
+  const float gwInv = static_cast<float>(kGridCols) / (max_x - min_x), ghInv = static_cast<float>(kGridRows) / (max_y - min_y);
+  struct CamGrid {
+    std::vector<int>     gidx;
+    std::vector<uint8_t> gcx, gcy;
+    int                  ng = 0;
+  } grids[2];
+  for (int cam = 0; cam < 2; cam++) {
+    const orbx_keypoint_t* kp = cur_kp + (cam ? nleft : 0);
+    const int              m  = cam ? nright : nleft;
+    std::vector<int>       cellCount(kGridCols * kGridRows + 1, 0), cellOf(m, -1);
+    for (int i = 0; i < m; i++) {
+      const int posX = (int)std::round((kp[i].x - min_x) * gwInv), posY = (int)std::round((kp[i].y - min_y) * ghInv);
+      if (posX < 0 || posX >= kGridCols || posY < 0 || posY >= kGridRows) continue;
+      cellOf[i] = posX * kGridRows + posY;
+      cellCount[cellOf[i] + 1]++;
+    }
+    for (int c = 0; c < kGridCols * kGridRows; c++) cellCount[c + 1] += cellCount[c];
+    CamGrid& G = grids[cam];
+    G.ng       = cellCount[kGridCols * kGridRows];
+    G.gidx.resize(G.ng + 1), G.gcx.resize(G.ng + 1), G.gcy.resize(G.ng + 1);
+    std::vector<int> fill(cellCount.begin(), cellCount.end() - 1);
+    for (int i = 0; i < m; i++)
+      if (cellOf[i] >= 0) {
+        const int p2 = fill[cellOf[i]]++;
+        G.gidx[p2]   = i;
+        G.gcx[p2]    = (uint8_t)(cellOf[i] / kGridRows);
+        G.gcy[p2]    = (uint8_t)(cellOf[i] % kGridRows);
+      }
+  }
+  hipStream_t  s       = h->stream;
+  const size_t inBytes = (size_t)n1 * (32 + 2 * (8 + 4 + 4 + 1)) + (size_t)n * (32 + sizeof(orbx_keypoint_t) + 1 + 4 + 6) + (size_t)nlevels * 4 + 16 * 32;
+  if (h->in.reserve(inBytes) || h->out.reserve((size_t)(n + 4) * 4 + 64) || h->topk.ensure((size_t)(2 * n1 + 2) * kTopK) || h->nvalid.ensure(2 * n1 + 2)) return -3;
+  Arena&        in = h->in;
+  MapTwoCamArgs a;
+  memset(&a, 0, sizeof(a));
+  const uint8_t*         dDesc = in.put(cur_desc, (size_t)n * 32);
+  const orbx_keypoint_t* dKp   = in.put(cur_kp, n);
+  const uint8_t*         dOcc  = cur_occupied ? in.put(cur_occupied, n) : nullptr;
+  const uint8_t*         dMp   = in.put(mp_desc, (size_t)n1 * 32);
+  const float*           dSf   = in.put(scale_factors, nlevels);
+  int D = th_dist + 1;  // a runner-up at distance D vetoes a best d1 <= th only if d1 > ratio * D (see proj_single)
+  while (D < 257 && (float)th_dist > ratio * (float)D) D++;
+  for (int cam = 0; cam < 2; cam++) {
+    ProjArgs& v = cam ? a.R : a.L;
+    CamGrid&  G = grids[cam];
+    v.d1 = dMp, v.d2 = dDesc + (size_t)(cam ? nleft : 0) * 32, v.kp2 = dKp + (cam ? nleft : 0);
+    v.occupied = dOcc ? dOcc + (cam ? nleft : 0) : nullptr;
+    v.g_idx = in.put(G.gidx.data(), G.ng), v.g_cx = in.put(G.gcx.data(), G.ng), v.g_cy = in.put(G.gcy.data(), G.ng);
+    v.uv = in.put(cam ? uv_r : uv_l, (size_t)2 * n1), v.radius1 = in.put(cam ? radius_r : radius_l, n1), v.oct1 = in.put(cam ? level_r : level_l, n1);
+    v.valid1 = in.put(cam ? valid_r : valid_l, n1);
+    v.mode = 1, v.ratio = ratio, v.dstar = D, v.sf = dSf;
+    v.n1 = n1, v.n2 = cam ? nright : nleft, v.ng = G.ng, v.th = 1.0f, v.minX = min_x, v.minY = min_y, v.gwInv = gwInv, v.ghInv = ghInv;
+    v.thDist = th_dist, v.topk = h->topk.p + (size_t)cam * n1 * kTopK, v.nvalid = h->nvalid.p + (size_t)cam * n1;
+  }
+  a.l2r = left_to_right ? in.put(left_to_right, nleft) : nullptr, a.r2l = right_to_left ? in.put(right_to_left, nright) : nullptr;
+  a.nleft = nleft, a.n = n;
+  if (!in.ok()) return -3;
+  HIP_TRYM(hipMemcpyAsync(in.d, in.h, in.off, hipMemcpyHostToDevice, s));
+  Arena& out = h->out;
+  a.nmatches = out.put((const int*)nullptr, 4), a.mp_of_cur = out.put((const int*)nullptr, n);
+  if (!out.ok()) return -3;
+  if (n1 > 0) {
+    hipLaunchKernelGGL(k_proj_topk, dim3((n1 + 3) / 4), dim3(256), 0, s, a.L);
+    hipLaunchKernelGGL(k_proj_topk, dim3((n1 + 3) / 4), dim3(256), 0, s, a.R);
+  }
+  hipLaunchKernelGGL(k_map_two_cam_resolve, dim3(1), dim3(64), 0, s, a);
+  HIP_TRYM(hipGetLastError());
+  HIP_TRYM(hipMemcpyAsync(out.h, out.d, out.off, hipMemcpyDeviceToHost, s));
+  HIP_TRYM(hipStreamSynchronize(s));
+  if (n) memcpy(mp_of_cur, out.host_of(a.mp_of_cur), (size_t)n * 4);
+  return *out.host_of(a.nmatches);
+}
+
 // the windowed search of SearchByProjection(KeyFrame*, Sim3f&, ...) / Fuse / SearchBySim3 on arrays (include/orbx.h)
 int orbm_search_in_windows(orbm_t* h, const uint8_t* q_desc, const float* q_uv, const float* q_ur, const int* q_level, const uint8_t* q_valid, int n1,
                            const uint8_t* t_desc, const orbx_keypoint_t* t_kp, const float* t_u_right, const uint8_t* t_occupied, int n2,

@@ -190,6 +190,29 @@ class ORBmatcher:
         )
         return n, com, moc
 
+    def SearchByProjectionMapPointsTwoCameras(self, mp_desc, left, right, cur_kps, cur_desc, nleft, scale_factors, bounds, cur_occupied=None,
+                                              left_to_right=None, right_to_left=None):
+        """SearchByProjection(Frame&, vector<MapPoint*>&, th, ...) for a two-camera frame (src/ORBmatcher.cc:139-146, 152-226).
+        left / right = (uv[n1,2], level[n1], radius[n1], valid[n1]) per camera (see include/orbx.h); cur_kps / cur_desc hold the left keys
+        [0, nleft) followed by the right keys.  Returns (nmatches, mp_of_cur[n])."""
+        d1 = np.ascontiguousarray(mp_desc, np.uint8).reshape(-1, 32)
+        d2 = np.ascontiguousarray(cur_desc, np.uint8).reshape(-1, 32)
+        kp = np.ascontiguousarray(cur_kps, _lib.KP_DTYPE)
+        n1, n = len(d1), len(d2)
+        cams = []
+        for uv, lv, rad, va in (left, right):
+            cams += [np.ascontiguousarray(uv, np.float32).reshape(-1, 2), np.ascontiguousarray(lv, np.int32), np.ascontiguousarray(rad, np.float32),
+                     np.ascontiguousarray(va, np.uint8)]
+        occ = None if cur_occupied is None else np.ascontiguousarray(cur_occupied, np.uint8)
+        l2r = None if left_to_right is None else np.ascontiguousarray(left_to_right, np.int32)
+        r2l = None if right_to_left is None else np.ascontiguousarray(right_to_left, np.int32)
+        sf = np.ascontiguousarray(scale_factors, np.float32)
+        out = np.zeros(n, np.int32)
+        nm = check(_lib.lib().orbm_search_by_projection_map_two_cameras(self._h, ptr(d1), n1, *[ptr(c) for c in cams], ptr(d2), ptr(kp), n, int(nleft), ptr(occ),
+                                                                        ptr(l2r), ptr(r2l), ptr(sf), len(sf), self.mfNNratio, *[float(b) for b in bounds], self.TH_HIGH,
+                                                                        ptr(out)), "orbm_search_by_projection_map_two_cameras")
+        return nm, out
+
     def SearchByProjectionKeyFrame(self, kf_mp_desc, mp_uv, mp_level, kf_angle, cur_kps, cur_desc, scale_factors, th, ORBdist, bounds, mp_valid=None,
                                    cur_occupied=None):
         """SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, sAlreadyFound, th, ORBdist) (src/ORBmatcher.cc:1910-2036), the relocalisation

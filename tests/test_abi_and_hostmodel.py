@@ -192,6 +192,8 @@ def test_bad_arguments_are_rejected_before_the_device():
     assert L.orbx_undistort_keypoints(None, None, 0, None, None, 0, None) == -2
     assert L.orbm_search_by_projection(None, None, None, None, None, None, None, 0, None, None, None, None, 0, None, 8, 15.0, 0, 0.0, 0.0, 1.0, 0.0, 1.0, 100, 1, None, None) == -2
     assert L.orbm_search_by_projection_map(None, None, None, None, None, None, None, 0, None, None, None, None, 0, None, 8, 0.8, 0.0, 1.0, 0.0, 1.0, 100, None, None) == -2
+    assert L.orbm_match_groups_two_cameras(None, None, 0, None, 0, 0, 1, None, None, None, None, None, None, None, 50, 0.7, 0, None) == -2
+    assert L.orbm_search_by_projection_map_two_cameras(None, None, 0, *([None] * 10), 0, 0, None, None, None, None, 8, 0.8, 0.0, 1.0, 0.0, 1.0, 100, None) == -2
     assert L.orbm_assign_features_to_grid_device(None, None, None, 1, 16, 0.0, 1.0, 0.0, 1.0, None, None, None, None, None) == -2
     assert L.orbm_search_in_windows(None, None, None, None, None, None, 0, None, None, None, None, 0, None, None, 8, 4.0, 0, 0.0, 1.0, 0.0, 1.0, 50, None) == -2
     assert L.orbm_search_in_windows(None, None, None, None, None, None, 0, None, None, None, None, 0, None, None, 8, 4.0, 2, 0.0, 1.0, 0.0, 1.0, 50, None) == -2  # claim is 0 / 1

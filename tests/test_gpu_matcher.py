@@ -547,3 +547,49 @@ def test_search_by_bow_two_cameras(oracle, synth, ori):
         n1, mt1 = m.SearchByBoW(kf, qa, None, qv, t, ta, None, f_nleft=nl)
         assert n0 == n1 and (mt0 == mt1).all()
     m.close()
+
+
+def test_search_by_projection_map_two_cameras(oracle):
+    """SearchByProjection(Frame&, vector<MapPoint*>&, ...) with F.Nleft != -1 (src/ORBmatcher.cc:139-146, 152-226) on random scenes:
+    clustered positions, few distinct descriptors (ties, same-level vetoes, exhausted truncated lists), random visibility per camera,
+    occupancy and stereo partner tables -- left and right searches interleave per point and the partner claims cross the cameras."""
+    from orbslam3_cpp_fork_amd.matcher import ORBmatcher
+
+    sf = (np.float32(1.2) ** np.arange(8)).astype(np.float32)
+    bounds = (0.0, 640.0, 0.0, 480.0)
+    total = vetoes = 0
+    for seed in range(20):
+        rng = np.random.default_rng(2000 + seed)
+        n1, nleft, nright = int(rng.integers(40, 600)), int(rng.integers(30, 500)), int(rng.integers(30, 500))
+        n = nleft + nright
+        ncl = int(rng.integers(3, 30))
+        centers = rng.uniform(40, 440, (ncl, 2))
+        cur = np.zeros(n, oracle.KP_DTYPE)
+        pc = centers[rng.integers(0, ncl, n)] + rng.normal(0, 12, (n, 2))
+        cur["x"], cur["y"] = pc[:, 0].astype(np.float32), pc[:, 1].astype(np.float32)
+        cur["octave"] = rng.integers(0, 8, n)
+        base = rng.integers(0, 256, (int(rng.integers(2, 40)), 32), dtype=np.uint8)
+        dcur = base[rng.integers(0, len(base), n)].copy()
+        dcur[:, 0] ^= rng.integers(0, 8, n).astype(np.uint8)
+        dmp = base[rng.integers(0, len(base), n1)].copy()
+        dmp[:, 1] ^= rng.integers(0, 4, n1).astype(np.uint8)
+        cams = []
+        for _ in range(2):
+            uv = (centers[rng.integers(0, ncl, n1)] + rng.normal(0, 10, (n1, 2))).astype(np.float32)
+            lv = rng.integers(0, 8, n1).astype(np.int32)
+            rad = (np.where(rng.random(n1) < 0.5, 2.5, 4.0) * rng.choice([1.0, 3.0])).astype(np.float32)
+            va = (rng.random(n1) < 0.75).astype(np.uint8)
+            cams.append((uv, lv, rad, va))
+        occ = (rng.random(n) < 0.1).astype(np.uint8)
+        l2r = np.where(rng.random(nleft) < 0.4, rng.integers(0, nright, nleft), -1).astype(np.int32)
+        r2l = np.where(rng.random(nright) < 0.4, rng.integers(0, nleft, nright), -1).astype(np.int32)
+        if seed % 5 == 0:
+            l2r = r2l = None
+        ratio = float(rng.choice([0.6, 0.8, 0.95]))
+        ref = oracle.search_by_projection_map_two_cameras(dmp, cams[0], cams[1], dcur, cur, nleft, sf, ratio, bounds, 100, occ, l2r, r2l)
+        m = ORBmatcher(ratio, True)
+        got = m.SearchByProjectionMapPointsTwoCameras(dmp, cams[0], cams[1], cur, dcur, nleft, sf, bounds, occ, l2r, r2l)
+        m.close()
+        assert got[0] == ref[0] and got[1].tolist() == ref[1].tolist(), seed
+        total += ref[0]
+    assert total > 1000
