@@ -142,6 +142,33 @@ class ORBmatcher {
     return n;
   }
 
+  // The same search for a two-camera frame (F.Nleft != -1, src/ORBmatcher.cc:139-146, 152-226): one set of per-point arrays per camera
+  // (the ...R members of MapPoint for the right one; radius without the th factor there, :158); curDesc / curKeys = left keys [0, nleft)
+  // then right keys (mvKeys, mvKeysRight); leftToRight / rightToLeft = F.mvLeftToRightMatch / mvRightToLeftMatch.  mpOfCur[j] = map point
+  // that F.mvpMapPoints[j] received (-1 = untouched): one point may land on up to four features.
+  struct CameraView {
+    std::vector<orbx_cv::Point2f> uv;
+    std::vector<int>              level;
+    std::vector<float>            radius;
+    std::vector<unsigned char>    valid;
+  };
+  int SearchByProjectionMapPointsTwoCamerasArrays(const orbx_cv::Mat& mpDesc, const CameraView& left, const CameraView& right, const orbx_cv::Mat& curDesc,
+                                                  const std::vector<orbx_cv::KeyPoint>& curKeys, int nleft, const std::vector<unsigned char>* curOccupied,
+                                                  const std::vector<int>* leftToRight, const std::vector<int>* rightToLeft,
+                                                  const std::vector<float>& scaleFactors, const float bounds[4], std::vector<int>& mpOfCur) {
+    const int n1 = (int)left.level.size(), n = (int)curKeys.size();
+    mpOfCur.assign(n, -1);
+    std::vector<uint8_t> d1 = pack(mpDesc), d2 = pack(curDesc);
+    int nm = orbm_search_by_projection_map_two_cameras(
+        h_, d1.data(), n1, reinterpret_cast<const float*>(left.uv.data()), left.level.data(), left.radius.data(), left.valid.data(),
+        reinterpret_cast<const float*>(right.uv.data()), right.level.data(), right.radius.data(), right.valid.data(), d2.data(),
+        reinterpret_cast<const orbx_keypoint_t*>(curKeys.data()), n, nleft, curOccupied ? curOccupied->data() : nullptr,
+        leftToRight ? leftToRight->data() : nullptr, rightToLeft ? rightToLeft->data() : nullptr, scaleFactors.data(), (int)scaleFactors.size(), mfNNratio,
+        bounds[0], bounds[1], bounds[2], bounds[3], TH_HIGH, mpOfCur.data());
+    if (nm <= -2) throw std::runtime_error(std::string("orbm_search_by_projection_map_two_cameras: ") + orbx_last_error());
+    return nm;
+  }
+
   // Array core of SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const std::set<MapPoint*>& sAlreadyFound, th, ORBdist)
   // (src/ORBmatcher.cc:1910-2036), the relocalisation search: the Frame-to-Frame core on predicted levels.  mpLevel[i] =
   // PredictScale(dist3D, &CurrentFrame), kfAngle[i] = pKF->mvKeysUn[i].angle, mpValid[i] = MapPoint present, not bad, not in
