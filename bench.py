@@ -32,6 +32,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 PCIE_PEAK_GBS = 63.0   # PCIe Gen5 x16 spec (same guide)
+PCIE_MEASURED_H2D_GBS = 57.0  # best single pinned copy measured on the GPU box (tools/dbg_pcie.py)
 # wave64 VALU instruction = 2 cycles on a SIMD-32 (same guide, "Wave scheduling"): 256 CUs x 4 SIMDs x 2.4 GHz / 2
 VALU_PEAK_GINST = 256 * 4 * 2.4 / 2
 
@@ -624,7 +625,7 @@ def main():
         h_imgs = [pinned_array((B, rows, cols), np.uint8) for _ in range(2)]
         h_imgs[0][:] = frames_np
         h_imgs[1][:] = frames_np[:, ::-1, :]
-        NH, depth = 1, 3  # one handle, three chunks in flight: the path is bound by the H2D copies (two handles side by side measured 156 k against 160 k frames/s)
+        NH, depth = int(os.environ.get("ORBX_BENCH_HOST_HANDLES", "1")), int(os.environ.get("ORBX_BENCH_HOST_DEPTH", "3"))  # one handle, three chunks in flight: the path is bound by the H2D copies (two or three handles side by side, ORBX_BENCH_HOST_HANDLES, measured 157-161 k against 167 k frames/s)
 
         class HostLane:
             def __init__(self):
@@ -684,6 +685,8 @@ def main():
             "value": round(total_frames_per_step * args.steps / dth, 2), "unit": "frames/s", "ms_per_step": round(dth / args.steps * 1e3, 4),
             "h2d_GBps_per_gpu": round(in_b * args.steps / dth / 1e9, 2), "d2h_GBps_per_gpu": round(out_b * args.steps / dth / 1e9, 2),
             "pcie_limit_frames_per_s_per_gpu": round(PCIE_PEAK_GBS * 1e9 / (rows * cols), 1),
+            # what one large pinned host -> device copy reaches on this pool with nothing else running (tools/dbg_pcie.py: 57 GB/s)
+            "h2d_measured_limit_frames_per_s_per_gpu": round(PCIE_MEASURED_H2D_GBS * 1e9 / (rows * cols), 1),
             "what": "same steps from pinned host memory via orbx_extract_async / orbx_wait (3 chunks in flight): timed region = H2D of every frame + "
                     "kernels + D2H of every fixed-capacity keypoint / descriptor / count record and of the match lists; two distinct chunks alternate",
             "keypoints_per_frame": float(hl[0].h_cnt[hl[0].last][:, 0].mean()),
