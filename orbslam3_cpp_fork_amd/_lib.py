@@ -32,6 +32,7 @@ SIGNATURES = {
     "orbx_set_input_resize": (_i, [_vp, _i, _i]),
     "orbx_max_keypoints": (_i, [_vp, _i, _i]),
     "orbx_set_tap_contraction": (_i, [_vp, _i]),
+    "orbx_set_graph_replay": (_i, [_vp, _i]),
     "orbx_extract": (_i, [_vp, _vp, _i, _i, _sz, _i, _i, _vp, _vp, _i, _ip]),
     "orbx_extract_batch_device": (_i, [_vp, _vp, _i, _i, _i, _sz, _sz, _i, _i, _vp, _vp, _vp, _i, _vp]),
     "orbx_stream_create": (_vp, [_i]),

@@ -41,12 +41,15 @@ const signed char kPatternHost[1024] = {
 #include "orb_pattern.inc"
 };
 
+static unsigned long long g_allocEpoch = 0;  // bumped by every (re)allocation of a device buffer of any handle
+
 template <class T>
 struct DevBuf {
   T*     p = nullptr;
   size_t n = 0;
   int    ensure(size_t count) {
     if (count <= n) return 0;
+    g_allocEpoch++;  // a recorded hipGraph of orbx_extract holds device addresses: any reallocation retires it (GraphKey::epoch)
     if (p) hipFree(p);
     p = nullptr;
     n = 0;
@@ -152,6 +155,21 @@ struct orbx_extractor {
   DevBuf<int4>    dOutIdx;
   DevBuf<uint16_t> dNodeOf, dD, dDIndex, dPushOff, dMultiOff, dKeptRank, dVA, dVB;
   int              octLdsNodeCap = 0, octLdsPtsCap = 0, octLdsBytes = 0;  // dynamic LDS plan of k_octree (makeGeometry)
+  struct GraphKey {
+    int            rows, cols;
+    size_t         step;
+    int            lap0, lap1, need;
+    const uint8_t *    src, *dst;
+    int                tapMode, inW, inH;
+    unsigned long long epoch;
+    bool operator==(const GraphKey& o) const {
+      return rows == o.rows && cols == o.cols && step == o.step && lap0 == o.lap0 && lap1 == o.lap1 && need == o.need && src == o.src && dst == o.dst &&
+             tapMode == o.tapMode && inW == o.inW && inH == o.inH && epoch == o.epoch;
+    }
+  };
+  bool           graphReplay = true, graphSeen = false;  // orbx_extract as a replayed hipGraph (orbx_set_graph_replay)
+  GraphKey       graphKey{};
+  hipGraphExec_t graphExec = nullptr;
   int              octLatencyFrames = 8;  // up to this many frames per call the quadtree runs a workgroup, not a wave, per (frame, level)
   DevBuf<uint32_t>           dSlots, dCand, dLvlKp;
   DevBuf<orbx::OtNode>       dNodesA, dNodesB;
@@ -719,6 +737,7 @@ int orbx_create(orbx_t** out, int nfeatures, float scale_factor, int nlevels, in
   h->nfeatures = nfeatures, h->nlevels = nlevels, h->iniTh = ini_th_fast, h->minTh = min_th_fast, h->scaleFactor = scale_factor;
   h->device = device_id;
   h->overlapMode = getenv("ORBX_OVERLAP_BLUR") ? atoi(getenv("ORBX_OVERLAP_BLUR")) : 0;
+  h->graphReplay = !(getenv("ORBX_GRAPH") != nullptr && atoi(getenv("ORBX_GRAPH")) == 0);  // on by default; ORBX_GRAPH=0 or orbx_set_graph_replay(h, 0) turns it off
   if (getenv("ORBX_OCT_LATENCY_FRAMES")) h->octLatencyFrames = atoi(getenv("ORBX_OCT_LATENCY_FRAMES"));  // tuning: 0 = always one wave per problem
   h->overlapBlur = h->overlapMode != 0;
   // src/ORBextractor.cc:409-440, exact float sequence
@@ -798,6 +817,7 @@ void orbx_destroy(orbx_t* h) {
     hipStreamSynchronize(h->stream);
     hipStreamDestroy(h->stream);
   }
+  if (h->graphExec) hipGraphExecDestroy(h->graphExec);
   if (h->hOut) hipHostFree(h->hOut);
   if (h->hIn) hipHostFree(h->hIn);
   for (hipStream_t st : {h->sIn, h->sOut})
@@ -878,6 +898,14 @@ int orbx_set_tap_contraction(orbx_t* h, int mode) {
   return 0;
 }
 
+int orbx_set_graph_replay(orbx_t* h, int enable) {
+  if (!h) return -2;
+  h->graphReplay = enable != 0;
+  if (!h->graphReplay && h->graphExec) hipGraphExecDestroy(h->graphExec), h->graphExec = nullptr;
+  h->graphSeen = false;
+  return 0;
+}
+
 int orbx_max_keypoints(orbx_t* h, int rows, int cols) {
   if (!h) return -2;
   hipSetDevice(h->device);
@@ -951,15 +979,7 @@ int orbx_extract(orbx_t* h, const uint8_t* img, int rows, int cols, size_t step_
     memcpy(h->hIn, img, rawBytes);
     hsrc = h->hIn;
   }
-  if ((int)step_bytes == pitch) {
-    HIP_TRY(hipMemcpyAsync(h->dStage.p, hsrc, rawBytes, hipMemcpyHostToDevice, h->stream));
-  } else {
-    if (h->dRaw.ensure(rawBytes)) return -3;
-    HIP_TRY(hipMemcpyAsync(h->dRaw.p, hsrc, rawBytes, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(hipMemcpy2DAsync(h->dStage.p, pitch, h->dRaw.p, step_bytes, cols, rows, hipMemcpyDeviceToDevice, h->stream));
-  }
-  rc = h->runResized(h->dStage.p, 1, rows, cols, pitch, (size_t)pitch * rows, lap0, lap1, h->dKpOut.p, h->dDescOut.p, h->dCounts.p, need, h->stream);
-  if (rc) return rc;
+  if ((int)step_bytes != pitch && h->dRaw.ensure(rawBytes)) return -3;
   // Device -> host: the count is not known before the copies are queued, so the whole fixed-capacity record block (<= 75 KB at 1000
   // features, 3 us of PCIe) lands in pinned memory behind the kernels and ONE synchronisation ends the call; the n live records
   // are then copied out on the host.  (Counts first, then two dependent blocking copies cost two more round trips: 0.26 -> 0.2x ms.)
@@ -970,9 +990,53 @@ int orbx_extract(orbx_t* h, const uint8_t* img, int rows, int cols, size_t step_
     HIP_TRY(hipHostMalloc((void**)&h->hOut, outBytes, hipHostMallocDefault));
     h->hOutCap = outBytes;
   }
-  HIP_TRY(hipMemcpyAsync(h->hOut, h->dCounts.p, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipMemcpyAsync(h->hOut + 16, h->dKpOut.p, kpBytes, hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipMemcpyAsync(h->hOut + 16 + kpBytes, h->dDescOut.p, dBytes, hipMemcpyDeviceToHost, h->stream));
+  auto enqueue = [&]() -> int {  // upload, the kernel chain, the three downloads: everything between the host copies in and out
+    if ((int)step_bytes == pitch) {
+      HIP_TRY(hipMemcpyAsync(h->dStage.p, hsrc, rawBytes, hipMemcpyHostToDevice, h->stream));
+    } else {
+      HIP_TRY(hipMemcpyAsync(h->dRaw.p, hsrc, rawBytes, hipMemcpyHostToDevice, h->stream));
+      HIP_TRY(hipMemcpy2DAsync(h->dStage.p, pitch, h->dRaw.p, step_bytes, cols, rows, hipMemcpyDeviceToDevice, h->stream));
+    }
+    const int rc2 = h->runResized(h->dStage.p, 1, rows, cols, pitch, (size_t)pitch * rows, lap0, lap1, h->dKpOut.p, h->dDescOut.p, h->dCounts.p, need, h->stream);
+    if (rc2) return rc2;
+    HIP_TRY(hipMemcpyAsync(h->hOut, h->dCounts.p, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->hOut + 16, h->dKpOut.p, kpBytes, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->hOut + 16 + kpBytes, h->dDescOut.p, dBytes, hipMemcpyDeviceToHost, h->stream));
+    return 0;
+  };
+  // Replay form (default; orbx_set_graph_replay(h, 0) / ORBX_GRAPH=0 turn it off): the enqueue sequence of a call is a pure function of this key, so the second
+  // call with the same key records it into a hipGraph (stream capture) and later calls replay it with one launch.
+  bool done = false;
+  if (h->graphReplay && !h->profiling && !h->overlapBlur && (rc = h->ensureWorkspace(er, ec, 1))) return rc;  // allocations happen before the key is taken
+  const orbx_extractor::GraphKey key{rows, cols, step_bytes, lap0, lap1, need, hsrc, h->hOut, h->tapMode, h->preW, h->preH, g_allocEpoch};
+  if (h->graphReplay && !h->profiling && !h->overlapBlur) {
+    if (h->graphExec && key == h->graphKey) {
+      HIP_TRY(hipGraphLaunch(h->graphExec, h->stream));
+      done = true;
+    } else if (h->graphSeen && key == h->graphKey) {  // seen once eagerly (every allocation has happened): record
+      if (h->graphExec) hipGraphExecDestroy(h->graphExec), h->graphExec = nullptr;
+      hipGraph_t graph = nullptr;
+      if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+        const int  rc3 = enqueue();
+        hipError_t e   = hipStreamEndCapture(h->stream, &graph);
+        if (rc3 == 0 && e == hipSuccess && graph && hipGraphInstantiate(&h->graphExec, graph, nullptr, nullptr, 0) == hipSuccess) {
+          HIP_TRY(hipGraphLaunch(h->graphExec, h->stream));
+          done = true;
+        } else {
+          (void)hipGetLastError();
+          h->graphExec = nullptr, h->graphReplay = false;  // this runtime cannot capture the sequence: stay eager
+        }
+        if (graph) hipGraphDestroy(graph);
+      } else {
+        (void)hipGetLastError();
+        h->graphReplay = false;
+      }
+    } else {
+      if (h->graphExec) hipGraphExecDestroy(h->graphExec), h->graphExec = nullptr;
+      h->graphKey = key, h->graphSeen = true;
+    }
+  }
+  if (!done && (rc = enqueue())) return rc;
   HIP_TRY(hipStreamSynchronize(h->stream));
   const int* counts = reinterpret_cast<const int*>(h->hOut);
   const int  n      = std::min(counts[0], need);

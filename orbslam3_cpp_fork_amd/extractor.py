@@ -64,6 +64,10 @@ class ORBextractor:
         """cv::resize(im, im, Size(new_cols, new_rows)) of System::Track* (src/System.cc:472-478) fused in front of the extractor; 0, 0 = off."""
         check(_lib.lib().orbx_set_input_resize(self._h, int(new_cols), int(new_rows)), "orbx_set_input_resize")
 
+    def set_graph_replay(self, enable):
+        """orbx_set_graph_replay: record the single-image call once (second call of a shape) and replay it as a hipGraph."""
+        check(_lib.lib().orbx_set_graph_replay(self._h, int(bool(enable))), "orbx_set_graph_replay")
+
     def set_tap_contraction(self, mode):
         """Tap-rotation evaluation of computeOrbDescriptor (include/orbx.h): 1 = reference as built on an FMA host (default), 0 = none, 2 = other."""
         check(_lib.lib().orbx_set_tap_contraction(self._h, int(mode)), "orbx_set_tap_contraction")

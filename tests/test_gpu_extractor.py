@@ -260,3 +260,46 @@ def test_gather_through_the_c_abi_single_rank():
     assert int(cnt[:, 0].min()) > 100
     assert torch.equal(ac[0], cnt) and torch.equal(ad[0], desc) and torch.equal(ak[0].view(torch.int32), kps.view(torch.int32))
     g.close()
+
+
+@pytest.mark.gpu
+def test_graph_replay_of_the_single_call(oracle):
+    """orbx_set_graph_replay: the third and later calls of one shape replay a captured hipGraph; results stay those of the eager call for
+    changing image contents, and a change of shape or lapping area falls back to eager and records again."""
+    from orbslam3_cpp_fork_amd import synth
+    from orbslam3_cpp_fork_amd.extractor import ORBextractor
+
+    ex = ORBextractor(500)
+    ref = ORBextractor(500)
+    ex.set_graph_replay(True)
+    ref.set_graph_replay(False)  # the eager sequence
+    frames = synth.make_stream(240, 320, 6, camera_idx=1)
+    for i, fr in enumerate(frames):  # call 0 eager, call 1 records, 2.. replay
+        a, b = ex(fr, None, (0, 1000)), ref(fr, None, (0, 1000))
+        assert a[0] == b[0] and a[1].tobytes() == b[1].tobytes() and a[2].tobytes() == b[2].tobytes(), i
+    big = synth.make_frame(376, 620, 2, 3)
+    for lap in ((0, 1000), (0, 1000), (0, 1000), (100, 300), (100, 300), (100, 300)):
+        a, b = ex(big, None, lap), ref(big, None, lap)
+        assert a[0] == b[0] and a[1].tobytes() == b[1].tobytes() and a[2].tobytes() == b[2].tobytes(), lap
+    for fr in frames[:3]:
+        a, b = ex(fr, None, (0, 1000)), ref(fr, None, (0, 1000))
+        assert a[1].tobytes() == b[1].tobytes()
+    # a batch call of another size on the same handle in between (workspace re-laid out, buffers reallocated): the recorded graph of the
+    # small shape must not be replayed on freed memory
+    import torch
+
+    B, rows, cols = 4, 480, 640
+    d = torch.from_numpy(synth.make_stream(rows, cols, B, camera_idx=3)).cuda()
+    cap = ex.max_keypoints(rows, cols)
+    kps = torch.zeros((B, cap, 7), device="cuda")
+    desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
+    cnt = torch.zeros((B, 2), dtype=torch.int32, device="cuda")
+    for rep in range(2):
+        for fr in frames[:3]:
+            a, b = ex(fr, None, (0, 1000)), ref(fr, None, (0, 1000))
+            assert a[0] == b[0] and a[1].tobytes() == b[1].tobytes() and a[2].tobytes() == b[2].tobytes()
+        ex.extract_batch_device(d, B, rows, cols, cols, rows * cols, kps, desc, cnt, cap, (0, 1000), stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+    ref.set_graph_replay(False)
+    a, b = ex(frames[0], None, (0, 1000)), ref(frames[0], None, (0, 1000))
+    assert a[1].tobytes() == b[1].tobytes() and a[2].tobytes() == b[2].tobytes()

@@ -8,7 +8,7 @@ OUT=$R/gpurun_out/qv_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU --output-format csv -d $OUT/pmc -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-pcie --lanes 1 > $OUT/bench_pmc.log 2>&1 || echo "step failed (rc $?)"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --no-cpu-baseline --no-pcie --lanes 1 > $OUT/bench.log 2>&1 || echo "step failed (rc $?)"
+[ -n "${QUICK_VALU_NO_TRACE:-}" ] || timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --no-cpu-baseline --no-pcie --lanes 1 > $OUT/bench.log 2>&1 || echo "step failed (rc $?)"
 cd $R
 python3 - "$OUT" <<'PY'
 import collections, csv, glob, re, sys
@@ -21,8 +21,8 @@ for r in csv.DictReader(open(f)):
         if m:
             agg[m.group(1)].append(float(r["Counter_Value"]))
 t = {}
-f = glob.glob(d + "/trace/**/*kernel_stats.csv", recursive=True)[0]
-for r in csv.DictReader(open(f)):
+ff = glob.glob(d + "/trace/**/*kernel_stats.csv", recursive=True)
+for r in (csv.DictReader(open(ff[0])) if ff else []):
     m = re.search(r"(k_\w+)", r["Name"])
     if m:
         t[m.group(1)] = (int(r["Calls"]), float(r["AverageNs"]) / 1e3)
