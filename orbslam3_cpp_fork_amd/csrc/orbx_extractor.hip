@@ -146,7 +146,7 @@ struct orbx_extractor {
   int             capB     = 0;
   int             lastB    = 0;
   orbx::Bufs      bufs{};
-  DevBuf<uint8_t> dPyr, dBlur, dNCh, dStage, dRaw, dDescOut;
+  DevBuf<uint8_t> dPyr, dBlur, dNCh, dStage, dRaw, dDescOut, dOutBlock;
   DevBuf<int>     dStereoSad;
   DevBuf<int2>    dXtab, dYtab;
   DevBuf<int4>    dCellDesc;
@@ -304,6 +304,10 @@ int orbx_extractor::makeGeometry(int rows, int cols) {
   g.totalSlots     = slotBase;
   g.totalNodes     = nodeBase;
   g.totalKp        = kpBase;
+  if (kpBase > orbx::kLayoutMaxRounds * 256) {
+    g_err = "more than 16384 keypoints per frame";
+    return -2;
+  }
   g.totalBlurTiles = tileBase;
   g.pyrBytes       = alignUp(pyrOff, 256);
   g.blurBytes      = alignUp(blurOff, 256);
@@ -837,7 +841,7 @@ void orbx_destroy(orbx_t* h) {
   if (h->evValid)
     for (auto& slot : h->ev)
       for (auto& e : slot) hipEventDestroy(e);
-  h->dPyr.release(), h->dBlur.release(), h->dStereoSad.release(), h->dRaw.release(), h->dPre.release(), h->dPreX.release(), h->dPreY.release(), h->dStage.release(), h->dDescOut.release(), h->dXtab.release(), h->dYtab.release();
+  h->dPyr.release(), h->dBlur.release(), h->dStereoSad.release(), h->dRaw.release(), h->dPre.release(), h->dPreX.release(), h->dPreY.release(), h->dStage.release(), h->dDescOut.release(), h->dOutBlock.release(), h->dXtab.release(), h->dYtab.release();
   h->dTiles.release(), h->dTileOrder.release(), h->dCellDesc.release(), h->dCellOrder.release(), h->dCellSlot.release(), h->dCellCount.release(), h->dNodeOf.release(), h->dCellOffs.release();
   h->dD.release(), h->dDIndex.release(), h->dNCh.release(), h->dPushOff.release(), h->dMultiOff.release();
   h->dKeptRank.release(), h->dVA.release(), h->dVB.release(), h->dCandCount.release(), h->dLvlCount.release(), h->dOutIdx.release();
@@ -960,8 +964,13 @@ int orbx_extract(orbx_t* h, const uint8_t* img, int rows, int cols, size_t step_
     return -2;
   }
   const int pitch = alignUp(cols, 64);
-  if (h->dStage.ensure((size_t)pitch * rows) || h->dKpOut.ensure(need) || h->dDescOut.ensure((size_t)need * 32) || h->dCounts.ensure(2))
-    return -3;
+  // the records of the call live in ONE device block laid out like the pinned host block they are copied to: {counts, pad to 16 B,
+  // keypoints[need], descriptors[need][32]} -- one download instead of three
+  const size_t kpBytes = (size_t)need * sizeof(orbx_keypoint_t), dBytes = (size_t)need * 32, outBytes = 16 + kpBytes + dBytes;
+  if (h->dStage.ensure((size_t)pitch * rows) || h->dOutBlock.ensure(outBytes)) return -3;
+  int* const             dCountsP = reinterpret_cast<int*>(h->dOutBlock.p);
+  orbx_keypoint_t* const dKpP     = reinterpret_cast<orbx_keypoint_t*>(h->dOutBlock.p + 16);
+  uint8_t* const         dDescP   = h->dOutBlock.p + 16 + kpBytes;
   // Host -> device as ONE linear copy (a pitched copy from pageable memory degenerates to a row-by-row transfer: 3 ms for a
   // 1241-px-wide image), then, if the caller's step is not the 64-byte aligned pitch the kernels like, a device-side repitch.
   // The caller's buffer is pageable: the runtime would stage it through its own pinned chunks with a synchronisation per chunk.
@@ -983,7 +992,6 @@ int orbx_extract(orbx_t* h, const uint8_t* img, int rows, int cols, size_t step_
   // Device -> host: the count is not known before the copies are queued, so the whole fixed-capacity record block (<= 75 KB at 1000
   // features, 3 us of PCIe) lands in pinned memory behind the kernels and ONE synchronisation ends the call; the n live records
   // are then copied out on the host.  (Counts first, then two dependent blocking copies cost two more round trips: 0.26 -> 0.2x ms.)
-  const size_t kpBytes = (size_t)need * sizeof(orbx_keypoint_t), dBytes = (size_t)need * 32, outBytes = 16 + kpBytes + dBytes;
   if (h->hOutCap < outBytes) {
     if (h->hOut) hipHostFree(h->hOut);
     h->hOut = nullptr, h->hOutCap = 0;
@@ -997,11 +1005,9 @@ int orbx_extract(orbx_t* h, const uint8_t* img, int rows, int cols, size_t step_
       HIP_TRY(hipMemcpyAsync(h->dRaw.p, hsrc, rawBytes, hipMemcpyHostToDevice, h->stream));
       HIP_TRY(hipMemcpy2DAsync(h->dStage.p, pitch, h->dRaw.p, step_bytes, cols, rows, hipMemcpyDeviceToDevice, h->stream));
     }
-    const int rc2 = h->runResized(h->dStage.p, 1, rows, cols, pitch, (size_t)pitch * rows, lap0, lap1, h->dKpOut.p, h->dDescOut.p, h->dCounts.p, need, h->stream);
+    const int rc2 = h->runResized(h->dStage.p, 1, rows, cols, pitch, (size_t)pitch * rows, lap0, lap1, reinterpret_cast<orbx::KpRec*>(dKpP), dDescP, dCountsP, need, h->stream);
     if (rc2) return rc2;
-    HIP_TRY(hipMemcpyAsync(h->hOut, h->dCounts.p, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipMemcpyAsync(h->hOut + 16, h->dKpOut.p, kpBytes, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipMemcpyAsync(h->hOut + 16 + kpBytes, h->dDescOut.p, dBytes, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->hOut, h->dOutBlock.p, outBytes, hipMemcpyDeviceToHost, h->stream));
     return 0;
   };
   // Replay form (default; orbx_set_graph_replay(h, 0) / ORBX_GRAPH=0 turn it off): the enqueue sequence of a call is a pure function of this key, so the second

@@ -723,55 +723,89 @@ __global__ __launch_bounds__(kOctThreads) void k_octree_only(OtArgs a) {
 // order; keypoints whose scaled x lies in [lap0, lap1] fill the output from the back, the others from
 // the front.  One workgroup per frame computes every keypoint's output row.
 // ------------------------------------------------------------------------------------------------
+// Keypoint i (natural order) is handled by thread i % 256 in round i / 256: every load of a round is independent of every other, and
+// the rank of a "stereo" keypoint (the number of them before it) is a ballot inside the wave plus a prefix over (round, wave) counts
+// held in LDS -- two short rounds over the keypoints instead of two dependent walks of a per-thread chunk.
+constexpr int kLayoutMaxRounds = 64;  // x 256 keypoints per frame (host-checked against totalKp)
+
 __global__ __launch_bounds__(256) void k_layout(Bufs b, FrameGeom g, int lap0, int lap1, int* counts, int cap) {
-  __shared__ int scratch[80];
-  const int      f = blockIdx.x;
-  DevCtx         c;
-  c.tid = threadIdx.x, c.nt = 256, c.lds = scratch;
-  const int* lc = b.lvlCount + (long long)f * g.nlevels;
-  int        n  = 0;
-  int        lbase[kMaxLevels + 1];
-  for (int l = 0; l < g.nlevels; l++) {
-    lbase[l] = n;
-    n += lc[l];
+  __shared__ int sLbase[kMaxLevels + 1];
+  __shared__ int sCnt[kLayoutMaxRounds * 4 + 1];  // stereo keypoints per (round, wave), then their exclusive prefix
+  const int      f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int*     lc = b.lvlCount + (long long)f * g.nlevels;
+  if (tid == 0) {
+    int n0 = 0;
+    for (int l = 0; l < g.nlevels; l++) {
+      sLbase[l] = n0;
+      n0 += lc[l];
+    }
+    sLbase[g.nlevels] = n0;
   }
-  lbase[g.nlevels] = n;
-  const uint32_t* kp  = b.lvlKp + (long long)f * g.totalKp;
-  int4*           oix = b.outIdx + (long long)f * g.totalKp * 2;
-  int             lo, hi;
-  ot_chunk(c, n, &lo, &hi);
-  uint32_t rOut = 0;
-  int      lOut = 0;
+  __syncthreads();
+  const int       n      = sLbase[g.nlevels];
+  const int       rounds = (n + 255) >> 8;
+  const uint32_t* kp     = b.lvlKp + (long long)f * g.totalKp;
+  int4*           oix    = b.outIdx + (long long)f * g.totalKp * 2;
+  uint32_t        rOut = 0;
+  int             lOut = 0;
   auto pred = [&](int i) -> bool {
     int l = 0;
-    while (l + 1 < g.nlevels && i >= lbase[l + 1]) l++;
-    const uint32_t r  = kp[g.lv[l].kpBase + (i - lbase[l])];
+    while (l + 1 < g.nlevels && i >= sLbase[l + 1]) l++;
+    const uint32_t r  = kp[g.lv[l].kpBase + (i - sLbase[l])];
     float          xs = (float)(ot_cx(r) + kMinBorder);
     if (l != 0) xs = xs * g.lv[l].scale;
     rOut = r, lOut = l;
     return xs >= (float)lap0 && xs <= (float)lap1;
   };
-  Int4 loc = {{0, 0, 0, 0}};
-  for (int i = lo; i < hi; i++) loc.v[0] += pred(i) ? 1 : 0;
-  Int4 tot;
-  Int4 ex     = c.scan4(loc, &tot);
-  int  stereo = ex.v[0];
-  for (int i = lo; i < hi; i++) {
-    const bool p   = pred(i);
-    const int  row = p ? (n - 1 - stereo) : (i - stereo);
-    // everything k_orient_describe needs about keypoint i
-    const LevelGeom& L  = g.lv[lOut];
-    const int        px = ot_cx(rOut) + kMinBorder, py = ot_cy(rOut) + kMinBorder;
-    const int        rawPitch = lOut == 0 ? b.img0Pitch : L.pitch;
-    const int        rawOrg   = (lOut == 0 ? 0 : L.pyrOff) + (py - kHalfPatch) * rawPitch + (px - kHalfPatch);
-    const int        blurOrg  = L.blurOff + (py - 18) * L.blurPitch + ((px - 18) & ~3);
-    oix[2 * i]     = make_int4((int)rOut, lOut | (row << 4), rawPitch, L.blurPitch);
-    oix[2 * i + 1] = make_int4(rawOrg, blurOrg, __float_as_int(L.scale), L.patchSize);
-    stereo += p ? 1 : 0;
+  for (int j = 0; j < rounds; j++) {
+    const int                i  = j * 256 + tid;
+    const unsigned long long bm = __ballot(i < n && pred(i));
+    if (lane == 0) sCnt[j * 4 + wave] = __popcll(bm);
   }
-  if (c.tid == 0) {
+  __syncthreads();
+  if (wave == 0) {  // exclusive prefix over the rounds * 4 counts (<= 256 of them: four per lane)
+    const int m = rounds * 4;
+    int       v[4], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      v[k] = lane * 4 + k < m ? sCnt[lane * 4 + k] : 0;
+      sum += v[k];
+    }
+    int inc = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int up = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += up;
+    }
+    int run = inc - sum;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      if (lane * 4 + k < m) sCnt[lane * 4 + k] = run;
+      run += v[k];
+    }
+    if (lane == 63) sCnt[kLayoutMaxRounds * 4] = inc;  // total
+  }
+  __syncthreads();
+  for (int j = 0; j < rounds; j++) {
+    const int                i  = j * 256 + tid;
+    const bool               p  = i < n && pred(i);
+    const unsigned long long bm = __ballot(p);
+    if (i < n) {
+      const int stereo = sCnt[j * 4 + wave] + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm, 0u));
+      const int row    = p ? (n - 1 - stereo) : (i - stereo);
+      // everything k_orient_describe needs about keypoint i
+      const LevelGeom& L  = g.lv[lOut];
+      const int        px = ot_cx(rOut) + kMinBorder, py = ot_cy(rOut) + kMinBorder;
+      const int        rawPitch = lOut == 0 ? b.img0Pitch : L.pitch;
+      const int        rawOrg   = (lOut == 0 ? 0 : L.pyrOff) + (py - kHalfPatch) * rawPitch + (px - kHalfPatch);
+      const int        blurOrg  = L.blurOff + (py - 18) * L.blurPitch + ((px - 18) & ~3);
+      oix[2 * i]     = make_int4((int)rOut, lOut | (row << 4), rawPitch, L.blurPitch);
+      oix[2 * i + 1] = make_int4(rawOrg, blurOrg, __float_as_int(L.scale), L.patchSize);
+    }
+  }
+  if (tid == 0) {
     counts[2 * f]     = n;
-    counts[2 * f + 1] = n - tot.v[0];  // monoIndex
+    counts[2 * f + 1] = n - sCnt[kLayoutMaxRounds * 4];  // monoIndex
   }
 }
 
