@@ -109,6 +109,7 @@ struct orbx_extractor {
   uint8_t*           hIn = nullptr;   // pinned take-off buffer of orbx_extract: the caller's (pageable) image is copied here first
   size_t             hInCap = 0;
   bool               overlapBlur = false;
+  bool               latencySideBlur = false;  // ORBX_LATENCY_SIDE_BLUR=1: calls with few frames run the blur on the side stream (measured: the fork and the join cost what the overlap saves)
   int                overlapMode = 0;  // ORBX_OVERLAP_BLUR: 1 = blur beside FAST, 2 = blur beside the quadtree
   bool               profiling = false;
   int                tapMode = 1;  // orbx_set_tap_contraction
@@ -642,7 +643,20 @@ int orbx_extractor::run(const uint8_t* d_imgs, int B, int rows, int cols, size_t
     HIP_TRY(hipEventRecord(evJoin, stream2));
     return 0;
   };
-  if (overlapBlur && overlapMode == 1 && (rc = forkBlur())) return rc;  // beside FAST (both VALU-bound: measured, no gain)
+  // Latency form (a handful of frames per call): nothing is resource-bound, the call is a chain of dependent launches -- the blur, which
+  // only needs the pyramid, can run on the side stream beside FAST -> quadtree -> layout and be joined before orientation.  Off by
+  // default: on MI355X the cross-stream fork and join cost ~10 us each, the 19 us blur they hide (0.201 -> 0.187 ms eager, but
+  // 0.176 -> 0.189 ms for the replayed graph).
+  const bool sideBlur = overlapBlur || (B <= octLatencyFrames && latencySideBlur);
+  if (sideBlur && !stream2) {
+    const uint32_t allCus[8] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+    if (hipExtStreamCreateWithCUMask(&stream2, 8, allCus) != hipSuccess || hipEventCreateWithFlags(&evFork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&evJoin, hipEventDisableTiming) != hipSuccess) {
+      g_err = "hipStreamCreate/hipEventCreate (side stream) failed";
+      return -3;
+    }
+  }
+  if (sideBlur && (!overlapBlur || overlapMode == 1) && (rc = forkBlur())) return rc;  // (throughput form, beside FAST: both VALU-bound, measured, no gain)
   if (prof) HIP_TRY(hipEventRecord(ev[1], s));
   static const bool useCells = getenv("ORBX_FAST_CELLS") != nullptr;  // first-generation kernel (one workgroup per cell), kept for A/B runs
   if (!useCells) {
@@ -700,7 +714,7 @@ int orbx_extractor::run(const uint8_t* d_imgs, int B, int rows, int cols, size_t
   if (prof) HIP_TRY(hipEventRecord(ev[3], s));
   hipLaunchKernelGGL(k_layout, dim3(B), dim3(256), 0, s, b, g, lap0, lap1, d_counts, cap);
   if (prof) HIP_TRY(hipEventRecord(ev[4], s));
-  if (overlapBlur)
+  if (sideBlur)
     HIP_TRY(hipStreamWaitEvent(s, evJoin, 0));  // join
   else
     launchBlur(s);
@@ -744,6 +758,7 @@ int orbx_create(orbx_t** out, int nfeatures, float scale_factor, int nlevels, in
   h->graphReplay = !(getenv("ORBX_GRAPH") != nullptr && atoi(getenv("ORBX_GRAPH")) == 0);  // on by default; ORBX_GRAPH=0 or orbx_set_graph_replay(h, 0) turns it off
   if (getenv("ORBX_OCT_LATENCY_FRAMES")) h->octLatencyFrames = atoi(getenv("ORBX_OCT_LATENCY_FRAMES"));  // tuning: 0 = always one wave per problem
   h->overlapBlur = h->overlapMode != 0;
+  if (getenv("ORBX_LATENCY_SIDE_BLUR")) h->latencySideBlur = atoi(getenv("ORBX_LATENCY_SIDE_BLUR")) != 0;
   // src/ORBextractor.cc:409-440, exact float sequence
   h->sf.resize(nlevels), h->sigma2.resize(nlevels), h->invSf.resize(nlevels), h->invSigma2.resize(nlevels), h->quota.resize(nlevels);
   h->sf[0] = 1.0f, h->sigma2[0] = 1.0f;
@@ -1013,9 +1028,9 @@ int orbx_extract(orbx_t* h, const uint8_t* img, int rows, int cols, size_t step_
   // Replay form (default; orbx_set_graph_replay(h, 0) / ORBX_GRAPH=0 turn it off): the enqueue sequence of a call is a pure function of this key, so the second
   // call with the same key records it into a hipGraph (stream capture) and later calls replay it with one launch.
   bool done = false;
-  if (h->graphReplay && !h->profiling && !h->overlapBlur && (rc = h->ensureWorkspace(er, ec, 1))) return rc;  // allocations happen before the key is taken
+  if (h->graphReplay && !h->profiling && (rc = h->ensureWorkspace(er, ec, 1))) return rc;  // allocations happen before the key is taken
   const orbx_extractor::GraphKey key{rows, cols, step_bytes, lap0, lap1, need, hsrc, h->hOut, h->tapMode, h->preW, h->preH, g_allocEpoch};
-  if (h->graphReplay && !h->profiling && !h->overlapBlur) {
+  if (h->graphReplay && !h->profiling) {
     if (h->graphExec && key == h->graphKey) {
       HIP_TRY(hipGraphLaunch(h->graphExec, h->stream));
       done = true;
