@@ -700,7 +700,7 @@ def main():
     if rank == 0:
         ab = algorithmic_bytes(rows, cols, nfeat)
         # dominant kernel class = the stage with the largest mean HIP-event duration in the timed region
-        kernels = {"pyramid": "k_resize_level", "fast": "k_fast_tiles", "octree": "k_octree", "blur": "k_blur_levels+k_blur_edges", "orient_describe": "k_orient_describe",
+        kernels = {"pyramid": "k_resize_level", "fast": "k_fast_tiles", "octree": "k_octree", "blur": "k_blur_all", "orient_describe": "k_orient_describe",
                    "match": "k_bf_topk+k_group_resolve"}
         # matcher: descriptors of both frames read once + one match index per query ((nq + nt) * 32 + nq * 4)
         ab["match"] = int(2 * cnt[:, 0].mean() * 32 + cnt[:, 0].mean() * 4)

@@ -624,8 +624,14 @@ int orbx_extractor::run(const uint8_t* d_imgs, int B, int rows, int cols, size_t
     const FrameGeom& gg = geom;
     int              edgeBlocks = 0;
     for (int l = al4 ? 0 : 1; l < gg.nlevels; l++) edgeBlocks += blur_edge_blocks(gg.lv[l]);
-    hipLaunchKernelGGL(k_blur_levels, dim3(8 * ((gg.totalBlurTiles + 7) / 8), B), dim3(256), 0, st, bufs, gg, l0a);
-    if (edgeBlocks > 0) hipLaunchKernelGGL(k_blur_edges, dim3(edgeBlocks, B), dim3(256), 0, st, bufs, gg, al4 ? 0 : 1);
+    static const bool split = getenv("ORBX_BLUR_SPLIT") != nullptr;  // A/B: interior and edge items as two launches
+    if (split || edgeBlocks == 0) {
+      hipLaunchKernelGGL(k_blur_levels, dim3(8 * ((gg.totalBlurTiles + 7) / 8), B), dim3(256), 0, st, bufs, gg, l0a);
+      if (edgeBlocks > 0) hipLaunchKernelGGL(k_blur_edges, dim3(edgeBlocks, B), dim3(256), 0, st, bufs, gg, al4 ? 0 : 1);
+    } else {
+      const int edgePad = 8 * ((edgeBlocks + 7) / 8);
+      hipLaunchKernelGGL(k_blur_all, dim3(edgePad + 8 * ((gg.totalBlurTiles + 7) / 8), B), dim3(256), 0, st, bufs, gg, l0a, al4 ? 0 : 1, edgeBlocks, edgePad);
+    }
     if (!al4) {
       const int items = ((gg.lv[0].w + 3) / 4) * ((gg.lv[0].h + kBlurEdgeRows - 1) / kBlurEdgeRows);
       hipLaunchKernelGGL(k_blur_level0_bytes, dim3((items + 255) / 256, B), dim3(256), 0, st, bufs, gg);

@@ -907,9 +907,9 @@ __device__ __forceinline__ void blur_strip(const uint8_t* __restrict__ src, int 
 // aligned-dword path (k_blur_levels: 56 registers, 8 waves per SIMD); the 2-3 edge groups of every strip need reflected
 // byte loads and live in a kernel of their own (k_blur_edges) so that their register appetite does not set the occupancy of
 // the other 98 %.  A level whose source is not 4-byte aligned (only the caller's level 0 can be) goes to the edge kernel whole.
-__global__ __launch_bounds__(256, 8) void k_blur_levels(Bufs b, FrameGeom g, int l0Aligned) {
-  const int f = blockIdx.y, tid = threadIdx.x;
-  int       t = xcd_item(blockIdx.x, g.totalBlurTiles), level = 0;
+__device__ __forceinline__ void blur_levels_block(const Bufs& b, const FrameGeom& g, int l0Aligned, int block, int f) {
+  const int tid = threadIdx.x;
+  int       t = xcd_item(block, g.totalBlurTiles), level = 0;
   if (t < 0) return;
   while (level + 1 < g.nlevels && t >= g.lv[level + 1].blurTileBase) level++;
   const LevelGeom& L = g.lv[level];
@@ -926,6 +926,8 @@ __global__ __launch_bounds__(256, 8) void k_blur_levels(Bufs b, FrameGeom g, int
   blur_strip<true, kBlurRows>(src, pitch, dst, L.blurPitch, L.w, L.h, gi * 4, strip * kBlurRows);
 }
 
+__global__ __launch_bounds__(256, 8) void k_blur_levels(Bufs b, FrameGeom g, int l0Aligned) { blur_levels_block(b, g, l0Aligned, blockIdx.x, blockIdx.y); }
+
 // Edge columns of the aligned levels: the first 4 columns and the last 4-8 columns (everything from 4 * (gLast + 1) on) of
 // every row.  A lane owns one ROW: its loads stay inside the first / last cache line of that row, so every edge line is
 // fetched once (column strips re-fetch each of them for every strip that overlaps it, scattered 128-byte reads that cost
@@ -935,10 +937,10 @@ constexpr int kBlurEdgeCols    = 12;   // 4 left + up to 8 right
 
 __host__ __device__ inline int blur_edge_blocks(const LevelGeom& L) { return (L.h + kBlurEdgeOutRows - 1) / kBlurEdgeOutRows; }
 
-__global__ __launch_bounds__(256) void k_blur_edges(Bufs b, FrameGeom g, int firstLevel) {
+__device__ __forceinline__ void blur_edges_block(const Bufs& b, const FrameGeom& g, int firstLevel, int block, int f) {
   __shared__ uint32_t hs[256][kBlurEdgeCols + 1];
-  const int f = blockIdx.y, tid = threadIdx.x;
-  int       t = blockIdx.x, level = firstLevel;
+  const int tid = threadIdx.x;
+  int       t = block, level = firstLevel;
   for (;; level++) {
     const int nb = blur_edge_blocks(g.lv[level]);
     if (t < nb || level + 1 >= g.nlevels) break;
@@ -1011,6 +1013,19 @@ __global__ __launch_bounds__(256) void k_blur_edges(Bufs b, FrameGeom g, int fir
   *reinterpret_cast<uint32_t*>(drow) = o[0] | (o[1] << 8) | (o[2] << 16) | (o[3] << 24);
   *reinterpret_cast<uint32_t*>(drow + xr0) = o[4] | (o[5] << 8) | (o[6] << 16) | (o[7] << 24);
   if (nRight > 4) *reinterpret_cast<uint32_t*>(drow + xr0 + 4) = o[8] | (o[9] << 8) | (o[10] << 16) | (o[11] << 24);
+}
+
+__global__ __launch_bounds__(256) void k_blur_edges(Bufs b, FrameGeom g, int firstLevel) { blur_edges_block(b, g, firstLevel, blockIdx.x, blockIdx.y); }
+
+// Both in one launch: the edge blocks (latency-bound: every lane walks one row of the first / last cache line) are dealt first and run
+// beside the interior blocks (VALU-bound) instead of after them.  edgePad = the edge block count rounded up to a multiple of 8, so that
+// the interior blocks keep their block -> XCD mapping.
+__global__ __launch_bounds__(256, 8) void k_blur_all(Bufs b, FrameGeom g, int l0Aligned, int firstEdgeLevel, int edgeBlocks, int edgePad) {
+  if ((int)blockIdx.x < edgePad) {
+    if ((int)blockIdx.x < edgeBlocks) blur_edges_block(b, g, firstEdgeLevel, blockIdx.x, blockIdx.y);
+  } else {
+    blur_levels_block(b, g, l0Aligned, blockIdx.x - edgePad, blockIdx.y);
+  }
 }
 
 // Unaligned level 0 (the caller's buffer is not 4-byte aligned / pitched): every group takes the byte-load strip.
