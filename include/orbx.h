@@ -113,7 +113,7 @@ int   orbx_wait(orbx_t* h, int ticket);
 
 /* orbx_extract as a replayed hipGraph (default on): the second orbx_extract call with the same (size, step, lapping area, source
  * buffer, device allocations) records its upload / 16 kernels / downloads by stream capture and later calls replay that graph with
- * one launch -- 0.201 -> 0.176 ms per 640x480 call on MI355X.  Any other shape, a reallocation of any device buffer, profiling or a
+ * one launch -- 0.191 -> 0.167 ms per 640x480 call on MI355X.  Any other shape, a reallocation of any device buffer, profiling or a
  * changed tap mode falls back to the eager sequence and records again.  enable = 0 keeps every call eager. */
 int orbx_set_graph_replay(orbx_t* h, int enable);
 
