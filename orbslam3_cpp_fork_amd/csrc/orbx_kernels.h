@@ -1092,8 +1092,11 @@ __global__ __launch_bounds__(256, 6) void k_orient_describe(Bufs b, FrameGeom g,
   if (f >= nframes) return;
   // the 256 pattern pairs (4 bytes each) go to LDS once per workgroup: the taps are then a short LDS read right where they are
   // needed instead of 8 registers held across the trigonometry
-  __shared__ uint32_t sPat[256];
-  sPat[threadIdx.x] = reinterpret_cast<const uint32_t*>(pat->v)[threadIdx.x];
+  __shared__ float4 sPat[256];  // (x0, y0, x1, y1) of pair i as floats: one 16-byte LDS read per pair instead of four byte-to-float conversions
+  {
+    const char4 c4    = __builtin_bit_cast(char4, reinterpret_cast<const uint32_t*>(pat->v)[threadIdx.x]);
+    sPat[threadIdx.x] = make_float4((float)c4.x, (float)c4.y, (float)c4.z, (float)c4.w);
+  }
   __syncthreads();
   const int i = (q % nbPerFrame) * kOdKpPerBlock + (threadIdx.x >> 6) * 2 + half;
   // (packed candidate, level, output row) were laid down by k_layout: one load, requested together with the frame's count
@@ -1121,11 +1124,22 @@ __global__ __launch_bounds__(256, 6) void k_orient_describe(Bufs b, FrameGeom g,
   const int      ax  = (px - 18) & ~3;  // aligned first column; the blurred level base and pitch are 64-byte aligned
   const uint8_t* blr = b.blur + (long long)f * g.blurBytes;  // uniform base + 32-bit lane offsets
   uint32_t       win[13];
+  // window dword idx = hl + 32 k sits at (row idx / 11, dword idx % 11): the division once, then +32 = +2 rows +10 dwords with a carry
+  int wr[13], wc[13];
+  {
+    int rr = hl / 11, cc = hl - rr * 11;
+#pragma unroll
+    for (int k = 0; k < 13; k++) {
+      wr[k] = rr, wc[k] = cc;
+      rr += 2, cc += 10;
+      if (cc >= 11) cc -= 11, rr += 1;
+    }
+  }
 #pragma unroll
   for (int k = 0; k < 13; k++) {  // unconditional (clamped) loads: nothing to branch around, all 13 in flight together
-    const int idx = min(hl + 32 * k, 37 * 11 - 1);
-    const int rr = idx / 11, cc = idx - rr * 11;
-    win[k]       = *reinterpret_cast<const uint32_t*>(blr + (uint32_t)(inf1.y + rr * blurPitch + cc * 4));
+    const bool in = hl + 32 * k < 37 * 11;
+    const int  rr = in ? wr[k] : 36, cc = in ? wc[k] : 10;
+    win[k]        = *reinterpret_cast<const uint32_t*>(blr + (uint32_t)(inf1.y + rr * blurPitch + cc * 4));
   }
 
   // ---- orientation on the raw level
@@ -1163,11 +1177,7 @@ __global__ __launch_bounds__(256, 6) void k_orient_describe(Bufs b, FrameGeom g,
   uint8_t*       pw  = patch[(threadIdx.x >> 6) * 2 + half];
 #pragma unroll
   for (int k = 0; k < 13; k++) {
-    const int idx = hl + 32 * k;
-    if (idx < 37 * 11) {
-      const int rr = idx / 11, cc = idx - rr * 11;
-      *reinterpret_cast<uint32_t*>(pw + rr * 44 + cc * 4) = win[k];
-    }
+    if (hl + 32 * k < 37 * 11) *reinterpret_cast<uint32_t*>(pw + wr[k] * 44 + wc[k] * 4) = win[k];
   }
   const float angle = fast_atan2_deg((float)m01, (float)m10);
   // ---- steered BRIEF on the blurred level
@@ -1184,8 +1194,8 @@ __global__ __launch_bounds__(256, 6) void k_orient_describe(Bufs b, FrameGeom g,
   uint32_t       mine = 0;  // half-lane w < 8 ends up with descriptor word w of its keypoint
 #pragma unroll
   for (int w = 0; w < 8; w++) {
-    const char4 p4 = __builtin_bit_cast(char4, sPat[w * 32 + hl]);
-    const float x0 = (float)p4.x, y0 = (float)p4.y, x1 = (float)p4.z, y1 = (float)p4.w;
+    const float4 p4 = sPat[w * 32 + hl];
+    const float  x0 = p4.x, y0 = p4.y, x1 = p4.z, y1 = p4.w;
     // tap rotation as the reference's compiler evaluates it (include/orbx.h: orbx_set_tap_contraction; wave-uniform switch)
     int r0, c0, r1, c1;
     if (tapMode == 1) {  // g++ -O3 -march=native on an FMA host: fma(x, b, y * a), fma(x, a, -(y * b))
