@@ -1124,22 +1124,19 @@ __global__ __launch_bounds__(256, 6) void k_orient_describe(Bufs b, FrameGeom g,
   const int      ax  = (px - 18) & ~3;  // aligned first column; the blurred level base and pitch are 64-byte aligned
   const uint8_t* blr = b.blur + (long long)f * g.blurBytes;  // uniform base + 32-bit lane offsets
   uint32_t       win[13];
-  // window dword idx = hl + 32 k sits at (row idx / 11, dword idx % 11): the division once, then +32 = +2 rows +10 dwords with a carry
-  int wr[13], wc[13];
+  // window dword idx = hl + 32 k sits at (row idx / 11, dword idx % 11) of the blurred level and -- the LDS copy being 11 dwords x 37
+  // rows back to back -- at byte 4 idx of the keypoint's LDS slice.  The division once, then +32 = +2 rows +10 dwords with a carry.
   {
     int rr = hl / 11, cc = hl - rr * 11;
+    uint32_t off = (uint32_t)(inf1.y + rr * blurPitch + cc * 4);
+    const uint32_t step = (uint32_t)(2 * blurPitch + 40), carry = (uint32_t)(blurPitch - 44);
 #pragma unroll
-    for (int k = 0; k < 13; k++) {
-      wr[k] = rr, wc[k] = cc;
-      rr += 2, cc += 10;
-      if (cc >= 11) cc -= 11, rr += 1;
+    for (int k = 0; k < 13; k++) {  // unconditional loads (the last round's lanes past dword 406 re-read it): all 13 in flight together
+      const bool in = hl + 32 * k < 37 * 11;
+      win[k]        = *reinterpret_cast<const uint32_t*>(blr + (in ? off : (uint32_t)(inf1.y + 36 * blurPitch + 40)));
+      off += step, cc += 10;
+      if (cc >= 11) cc -= 11, off += carry;
     }
-  }
-#pragma unroll
-  for (int k = 0; k < 13; k++) {  // unconditional (clamped) loads: nothing to branch around, all 13 in flight together
-    const bool in = hl + 32 * k < 37 * 11;
-    const int  rr = in ? wr[k] : 36, cc = in ? wc[k] : 10;
-    win[k]        = *reinterpret_cast<const uint32_t*>(blr + (uint32_t)(inf1.y + rr * blurPitch + cc * 4));
   }
 
   // ---- orientation on the raw level
@@ -1177,7 +1174,7 @@ __global__ __launch_bounds__(256, 6) void k_orient_describe(Bufs b, FrameGeom g,
   uint8_t*       pw  = patch[(threadIdx.x >> 6) * 2 + half];
 #pragma unroll
   for (int k = 0; k < 13; k++) {
-    if (hl + 32 * k < 37 * 11) *reinterpret_cast<uint32_t*>(pw + wr[k] * 44 + wc[k] * 4) = win[k];
+    if (hl + 32 * k < 37 * 11) *reinterpret_cast<uint32_t*>(pw + (hl + 32 * k) * 4) = win[k];
   }
   const float angle = fast_atan2_deg((float)m01, (float)m10);
   // ---- steered BRIEF on the blurred level
