@@ -283,7 +283,7 @@ __device__ __forceinline__ int popc_acc(uint32_t x, int acc) {
 }
 
 constexpr int kBfQueue     = 16;  // hits a lane may park between two merges
-constexpr int kBfFlushRows = 32;  // rows between two scheduled merges (power of two, multiple of 4)
+constexpr int kBfFlushRows = 64;  // rows between two scheduled merges (power of two, multiple of 4)
 
 // (A form that reads the rows into scalar registers instead -- wave-uniform s_load_dwordx8 from the constant address space, no LDS
 // tile -- was measured at 233 us against 205 us for this one on 256 x 1000 x 1000; so was splitting the rows over twice the waves.)
@@ -316,7 +316,8 @@ __global__ __launch_bounds__(256) void k_bf_topk(GroupArgs a0) {
   // the lane's next free slot is held as a byte offset (slot * 1024 + tid * 4, so the hit count is offset >> 10), the pruning bound is a
   // per-lane value (0 for a lane without a query: no distance is below it), and the row number enters as a scalar operand.
   unsigned char* const hitqBytes = reinterpret_cast<unsigned char*>(&hitq[0][0]);
-  const int            dlane     = active ? dstar : 0;
+  int                  dlane     = active ? dstar : 0;
+  bool                 tightened = false;
   uint32_t             qslot     = tid * 4;
   const uint32_t       qlimit    = (uint32_t)(kBfQueue - 4) * 1024u + (uint32_t)tid * 4u;  // above this a lane could overflow within four rows
   auto park = [&](int row, int d) {
@@ -338,6 +339,13 @@ __global__ __launch_bounds__(256) void k_bf_topk(GroupArgs a0) {
     }
     cnt += qn;
     qslot = tid * 4;
+    // Once the K-list is full, a later row (= a larger position) only enters it with a distance below the list's last one: the
+    // lane's bound shrinks to that distance and everything at or above it is no longer parked.  Hits skipped this way are not
+    // counted, so a lane that has tightened its bound reports "more candidates than listed" (all the resolve pass asks of nvalid).
+    if (k[kTopK - 1] != kEmpty) {
+      const int dLast = (int)(k[kTopK - 1] >> kPosBits);
+      if (dLast < dlane) dlane = dLast, tightened = true;
+    }
   };
   // stage tile 0
   auto stage = [&](int buf, int base) {
@@ -408,7 +416,7 @@ __global__ __launch_bounds__(256) void k_bf_topk(GroupArgs a0) {
     uint4* o = reinterpret_cast<uint4*>(a.topk + (size_t)e * kTopK);
     o[0]     = make_uint4(k[0], k[1], k[2], k[3]);
     o[1]     = make_uint4(k[4], k[5], k[6], k[7]);
-    a.nvalid[e] = cnt;
+    a.nvalid[e] = tightened ? max(cnt, kTopK + 1) : cnt;
   }
 }
 
