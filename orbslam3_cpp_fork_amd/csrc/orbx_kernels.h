@@ -92,6 +92,14 @@ __device__ __forceinline__ void resize_tile(const uint8_t* __restrict__ S, int s
   const int        tid = threadIdx.x;
   const int        dx0 = tileX * kRsTileW, dy0 = tileY * kRsTileH;
   const int        dxl = min(dx0 + kRsTileW, dw) - 1, dyl = min(dy0 + kRsTileH, dh) - 1;
+  // This thread's own table entries (4 destination columns, 2 destination rows) are requested first, together with the footprint
+  // lookups below: they do not depend on the staged tile, and behind the barrier they were one more exposed round trip per workgroup.
+  const int  dx  = dx0 + (tid & 31) * 4;
+  const int  dyA = dy0 + (tid >> 5) * 2;
+  int2       xts[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) xts[k] = xtab[min(dx + k, dw - 1)];
+  const int2 yts[2] = {ytab[min(dyA, dh - 1)], ytab[min(dyA + 1, dh - 1)]};
   // source footprint of the tile (tables are monotone)
   const int sxa = xtab[dx0].x & ~3;
   const int sxb = min(xtab[dxl].x + 1, sw - 1);
@@ -128,7 +136,6 @@ __device__ __forceinline__ void resize_tile(const uint8_t* __restrict__ S, int s
     }
   }
   __syncthreads();
-  const int dx = dx0 + (tid & 31) * 4;
   if (dx >= dw) return;
   // The four taps of a pixel sit at LDS offsets {0, 1, row, row + 1} from ONE address.  Where cv::resize clamps the second
   // column / row to the last source column / row its weight is 0 (fx = 0 / fy = 0 there), so the unclamped neighbour --
@@ -136,16 +143,16 @@ __device__ __forceinline__ void resize_tile(const uint8_t* __restrict__ S, int s
   int sx[4], a0[4], a1[4];
 #pragma unroll
   for (int k = 0; k < 4; k++) {
-    const int2 xt = xtab[min(dx + k, dw - 1)];
+    const int2 xt = xts[k];
     sx[k] = xt.x - sxa;
     a0[k] = (short)(xt.y & 0xffff);
     a1[k] = xt.y >> 16;
   }
 #pragma unroll
   for (int rr = 0; rr < 2; rr++) {
-    const int dy = dy0 + (tid >> 5) * 2 + rr;
+    const int dy = dyA + rr;
     if (dy >= dh) break;
-    const int2 yt = ytab[dy];
+    const int2 yt = yts[rr];
     const int  r0 = min(max(yt.x, 0), sh - 1) - sya;
     const int  r1 = CLAMP_ROWS ? min(max(yt.x + 1, 0), sh - 1) - sya : r0 + 1;
     const int  b0 = (short)(yt.y & 0xffff), b1 = yt.y >> 16;
