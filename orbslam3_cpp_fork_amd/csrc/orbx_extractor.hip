@@ -6,6 +6,8 @@
 // 755-775; OpenCV resize.cpp) so that every kernel is integer-only where the reference is.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -41,7 +43,7 @@ const signed char kPatternHost[1024] = {
 #include "orb_pattern.inc"
 };
 
-static unsigned long long g_allocEpoch = 0;  // bumped by every (re)allocation of a device buffer of any handle
+static std::atomic<unsigned long long> g_allocEpoch{0};  // bumped by every (re)allocation of a device buffer of any handle (handles may live on different host threads)
 
 template <class T>
 struct DevBuf {
@@ -1035,7 +1037,7 @@ int orbx_extract(orbx_t* h, const uint8_t* img, int rows, int cols, size_t step_
   // call with the same key records it into a hipGraph (stream capture) and later calls replay it with one launch.
   bool done = false;
   if (h->graphReplay && !h->profiling && (rc = h->ensureWorkspace(er, ec, 1))) return rc;  // allocations happen before the key is taken
-  const orbx_extractor::GraphKey key{rows, cols, step_bytes, lap0, lap1, need, hsrc, h->hOut, h->tapMode, h->preW, h->preH, g_allocEpoch};
+  const orbx_extractor::GraphKey key{rows, cols, step_bytes, lap0, lap1, need, hsrc, h->hOut, h->tapMode, h->preW, h->preH, g_allocEpoch.load()};
   if (h->graphReplay && !h->profiling) {
     if (h->graphExec && key == h->graphKey) {
       HIP_TRY(hipGraphLaunch(h->graphExec, h->stream));
