@@ -325,12 +325,10 @@ __global__ __launch_bounds__(kFastTileThreads) void k_fast_tiles(Bufs b, FrameGe
     // are never scored, so they already are)
     if (cx == 0) t[0] = t[3] = t[5] = 0;
     if (cx == iw - 1) t[2] = t[4] = t[7] = 0;
-    int m1 = 0, m2 = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-      m2 = max(m2, t[i] >= minTh ? t[i] : 0);  // (minThFAST may exceed iniThFAST: the reference does not check)
-      m1 = max(m1, t[i] >= iniTh ? t[i] : 0);
-    }
+    // the largest neighbour under a threshold th is max{t : t >= th} = (M >= th ? M : 0) with M the largest neighbour overall: one
+    // max over the eight instead of one per threshold (minThFAST may exceed iniThFAST: the reference does not check, nor does this)
+    const int M  = max(max(max(t[0], t[1]), max(t[2], t[3])), max(max(t[4], t[5]), max(t[6], t[7])));
+    const int m1 = M >= iniTh ? M : 0, m2 = M >= minTh ? M : 0;
     const bool f1 = s >= iniTh && s > m1, f2 = s >= minTh && s > m2;
     if (f1 | f2) {
       const int      idx = row * iw + cx;
