@@ -290,9 +290,19 @@ __global__ __launch_bounds__(kFastTileThreads) void k_fast_tiles(Bufs b, FrameGe
     }
     if (fill > 0) score_rec(lane < fill ? stg[lane] : 0xffffu, lane < fill);
   } else {
-  for (int k = tid; k < ncand; k += kFastTileThreads) {
-    const unsigned e = cand[k];
-    if (e != 0xffffu) score_one((int)(e >> 9), (int)(e & 511u));
+  // two listed candidates per lane: the two-pixel form of the score (both pixels' margins in the halves of one register, a min chain
+  // and a max chain) costs ~96 vector instructions per pixel against ~134 for the one-pixel, both-polarities form
+  for (int j = tid; 2 * j < ncand; j += kFastTileThreads) {
+    unsigned   e0 = cand[2 * j], e1 = 2 * j + 1 < ncand ? cand[2 * j + 1] : 0xffffu;
+    const bool v0 = e0 != 0xffffu, v1 = e1 != 0xffffu;
+    if (v0 | v1) {
+      e0 = v0 ? e0 : e1, e1 = v1 ? e1 : e0;
+      const int o0 = ((int)(e0 >> 9) + 3) * P + (int)(e0 & 511u), o1 = ((int)(e1 >> 9) + 3) * P + (int)(e1 & 511u);
+      int       s0, s1;
+      fast_score2(tile + o0, tile + o1, P, &s0, &s1);
+      if (v0) score[o0] = (uint8_t)(s0 >= lowTh ? s0 : 0);  // scores below both thresholds are never corners
+      if (v1) score[o1] = (uint8_t)(s1 >= lowTh ? s1 : 0);
+    }
   }
   }
   if (__ballot(ovf != 0)) {
