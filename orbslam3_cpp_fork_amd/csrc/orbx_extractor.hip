@@ -507,7 +507,12 @@ int orbx_extractor::makeGeometry(int rows, int cols) {
     int maxCap = 0;
     for (int l = 0; l < nlevels; l++) maxCap = std::max(maxCap, g.lv[l].nodeCap);
     const int fixed = kOctFixedInts * 4, nodeBytes = maxCap * kOctNodeBytes;
-    if (fixed + nodeBytes + 2 * 512 <= 20224) {
+    static const int ldsMode = getenv("ORBX_OCT_LDS") ? atoi(getenv("ORBX_OCT_LDS")) : 2;  // A/B: 0 = state in global memory, 1 = node arrays only, 2 = nodes + point labels
+    if (ldsMode == 0) {
+      octLdsNodeCap = 0, octLdsBytes = fixed, octLdsPtsCap = 0;
+    } else if (ldsMode == 1 && fixed + nodeBytes <= 65536) {
+      octLdsNodeCap = maxCap, octLdsBytes = fixed + nodeBytes, octLdsPtsCap = 0;
+    } else if (fixed + nodeBytes + 2 * 512 <= 20224) {
       octLdsNodeCap = maxCap, octLdsBytes = 20224, octLdsPtsCap = (octLdsBytes - fixed - nodeBytes) / 2;
     } else if (fixed + nodeBytes + 2 * 4096 <= 40960) {
       // larger quotas (2000 features: 30 KB of node state): 4 problems per CU, and 4096 point labels still ride along
