@@ -244,3 +244,50 @@ def test_stereo_matches_batch_device(oracle):
         assert nl == len(okl) and int(kept[f]) == n0 and n0 > 50
         assert (ur[f, :nl].cpu().numpy().view(np.uint32) == u0.view(np.uint32)).all()
         assert (dp[f, :nl].cpu().numpy().view(np.uint32) == d0.view(np.uint32)).all()
+
+
+@pytest.mark.gpu
+def test_full_chunk_properties_two_chunks_in_flight(oracle):
+    """BASELINE's chunk size (256 VGA frames) with two chunks in flight on streams that own their hardware queue: the 8 distinct frames of
+    the chunk equal the oracle, every repetition of a frame yields bit-identical records whatever its position in the batch and whichever
+    of the two concurrently running handles produced it (size-independent properties at full size: position invariance, determinism
+    under concurrency)."""
+    import torch
+
+    from orbslam3_cpp_fork_amd import _lib, synth
+    from orbslam3_cpp_fork_amd.extractor import ORBextractor
+
+    B, rows, cols, nd = 256, 480, 640, 8
+    base = synth.make_stream(rows, cols, nd, camera_idx=4)
+    order = np.random.default_rng(5).integers(0, nd, B)
+    order[:nd] = np.arange(nd)
+    d = torch.from_numpy(base[order]).cuda()
+    lanes = []
+    for _ in range(2):
+        ex = ORBextractor(1000)
+        cap = ex.max_keypoints(rows, cols)
+        st = _lib.lib().orbx_stream_create(0)
+        assert st
+        lanes.append((ex, st, torch.zeros((B, cap, 7), device="cuda"), torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda"),
+                      torch.zeros((B, 2), dtype=torch.int32, device="cuda")))
+    torch.cuda.synchronize()
+    for rep in range(2):
+        for ex, st, kps, desc, cnt in lanes:
+            ex.extract_batch_device(d, B, rows, cols, cols, rows * cols, kps, desc, cnt, cap, (0, 1000), stream=st)
+    torch.cuda.synchronize()
+    oex = oracle.OracleExtractor(1000, 1.2, 8, 20, 7)
+    ref = [oex(base[i], (0, 1000)) for i in range(nd)]
+    for ex, st, kps, desc, cnt in lanes:
+        c, k, dd = cnt.cpu().numpy(), kps.cpu().numpy().view(np.uint32), desc.cpu().numpy()
+        for f in range(B):
+            src = int(order[f])
+            n = int(c[f, 0])
+            assert n == len(ref[src][1]) and int(c[f, 1]) == ref[src][0]
+            assert (k[f, :n] == k[src, :n]).all() and (dd[f, :n] == dd[src, :n]).all()
+        for i in range(nd):
+            n = int(c[i, 0])
+            assert (dd[i, :n] == ref[i][2]).all()
+            assert (kps.cpu().numpy()[i, :n, 0] == ref[i][1]["x"]).all() and (kps.cpu().numpy()[i, :n, 3] == ref[i][1]["angle"]).all()
+    for ex, st, *_ in lanes:
+        ex.close()
+        _lib.lib().orbx_stream_destroy(st)
