@@ -150,7 +150,7 @@ struct orbx_extractor {
   int             lastB    = 0;
   orbx::Bufs      bufs{};
   DevBuf<uint8_t> dPyr, dBlur, dNCh, dStage, dRaw, dDescOut, dOutBlock;
-  DevBuf<int>     dStereoSad;
+  DevBuf<int>     dStereoSad, dStereoRowStart, dStereoRowIdx;
   DevBuf<int2>    dXtab, dYtab;
   DevBuf<int4>    dCellDesc;
   DevBuf<long long> dDbgT;
@@ -869,7 +869,7 @@ void orbx_destroy(orbx_t* h) {
   if (h->evValid)
     for (auto& slot : h->ev)
       for (auto& e : slot) hipEventDestroy(e);
-  h->dPyr.release(), h->dBlur.release(), h->dStereoSad.release(), h->dRaw.release(), h->dPre.release(), h->dPreX.release(), h->dPreY.release(), h->dStage.release(), h->dDescOut.release(), h->dOutBlock.release(), h->dXtab.release(), h->dYtab.release();
+  h->dPyr.release(), h->dBlur.release(), h->dStereoSad.release(), h->dStereoRowStart.release(), h->dStereoRowIdx.release(), h->dRaw.release(), h->dPre.release(), h->dPreX.release(), h->dPreY.release(), h->dStage.release(), h->dDescOut.release(), h->dOutBlock.release(), h->dXtab.release(), h->dYtab.release();
   h->dTiles.release(), h->dTileOrder.release(), h->dCellDesc.release(), h->dCellOrder.release(), h->dCellSlot.release(), h->dCellCount.release(), h->dNodeOf.release(), h->dCellOffs.release();
   h->dD.release(), h->dDIndex.release(), h->dNCh.release(), h->dPushOff.release(), h->dMultiOff.release();
   h->dKeptRank.release(), h->dVA.release(), h->dVB.release(), h->dCandCount.release(), h->dLvlCount.release(), h->dOutIdx.release();
@@ -1486,9 +1486,10 @@ int orbx_stereo_matches(orbx_t* left, orbx_t* right, const orbx_keypoint_t* kl, 
   DevBuf<KpRec>    dkl, dkr;
   DevBuf<uint8_t>  ddl, ddr;
   DevBuf<float>    du, dd;
-  DevBuf<int>      dsad, dkept;
+  DevBuf<int>      dsad, dkept, drow, dridx;
+  const bool       byRow = left->geom.rows <= kStereoMaxRows && nr > 0;
   if (dkl.ensure(nl) || dkr.ensure(nr + 1) || ddl.ensure((size_t)nl * 32) || ddr.ensure((size_t)nr * 32 + 32) || du.ensure(nl) || dd.ensure(nl) ||
-      dsad.ensure(nl) || dkept.ensure(1))
+      dsad.ensure(nl) || dkept.ensure(1) || (byRow && (drow.ensure(left->geom.rows + 2) || dridx.ensure(nr + 1))))
     return -3;
   HIP_TRY(hipMemcpyAsync(dkl.p, kl, (size_t)nl * sizeof(KpRec), hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemcpyAsync(ddl.p, dl, (size_t)nl * 32, hipMemcpyHostToDevice, s));
@@ -1506,6 +1507,10 @@ int orbx_stereo_matches(orbx_t* left, orbx_t* right, const orbx_keypoint_t* kl, 
   }
   a.pyrL = left->bufs.pyr, a.pyrR = right->bufs.pyr;
   a.uRight = du.p, a.depth = dd.p, a.sad = dsad.p;
+  if (byRow) {
+    a.rowStart = drow.p, a.rowIdx = dridx.p, a.rowBand = (int)std::ceil(2.0f * left->sf[left->nlevels - 1]) + 1;
+    hipLaunchKernelGGL(k_stereo_rows, dim3(1), dim3(256), 0, s, a);
+  }
   hipLaunchKernelGGL(k_stereo_match, dim3((nl + 3) / 4), dim3(256), 0, s, a, left->geom);
   hipLaunchKernelGGL(k_stereo_cut, dim3(1), dim3(256), 0, s, a, dkept.p);
   HIP_TRY(hipGetLastError());
@@ -1514,7 +1519,7 @@ int orbx_stereo_matches(orbx_t* left, orbx_t* right, const orbx_keypoint_t* kl, 
   HIP_TRY(hipMemcpyAsync(depth, dd.p, (size_t)nl * 4, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipMemcpyAsync(&kept, dkept.p, 4, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
-  dkl.release(), dkr.release(), ddl.release(), ddr.release(), du.release(), dd.release(), dsad.release(), dkept.release();
+  dkl.release(), dkr.release(), ddl.release(), ddr.release(), du.release(), dd.release(), dsad.release(), dkept.release(), drow.release(), dridx.release();
   return kept;
 }
 
@@ -1540,7 +1545,10 @@ int orbx_stereo_matches_batch_device(orbx_t* left, orbx_t* right, const orbx_key
   }
   if (nframes == 0) return 0;
   HIP_TRY(hipSetDevice(left->device));
-  if (left->dStereoSad.ensure((size_t)nframes * cap)) return -3;
+  const bool byRow = left->geom.rows <= kStereoMaxRows;
+  if (left->dStereoSad.ensure((size_t)nframes * cap) ||
+      (byRow && (left->dStereoRowStart.ensure((size_t)nframes * (left->geom.rows + 1) + 1) || left->dStereoRowIdx.ensure((size_t)nframes * cap))))
+    return -3;
   hipStream_t s = stream ? (hipStream_t)stream : left->stream;
   StereoArgs  a;
   memset(&a, 0, sizeof(a));
@@ -1549,6 +1557,10 @@ int orbx_stereo_matches_batch_device(orbx_t* left, orbx_t* right, const orbx_key
   a.pyrL = left->bufs.pyr, a.pyrR = right->bufs.pyr, a.uRight = d_u_right, a.depth = d_depth, a.sad = left->dStereoSad.p;
   a.cap = cap, a.countsL = d_counts_l, a.countsR = d_counts_r, a.img0StrideL = left->bufs.img0FrameStride;
   a.img0StrideR = right->bufs.img0FrameStride, a.pyrBytes = left->geom.pyrBytes;
+  if (byRow) {
+    a.rowStart = left->dStereoRowStart.p, a.rowIdx = left->dStereoRowIdx.p, a.rowBand = (int)std::ceil(2.0f * left->sf[left->nlevels - 1]) + 1;
+    hipLaunchKernelGGL(k_stereo_rows, dim3(nframes), dim3(256), 0, s, a);
+  }
   hipLaunchKernelGGL(k_stereo_match, dim3((cap + 3) / 4, nframes), dim3(256), 0, s, a, left->geom);
   hipLaunchKernelGGL(k_stereo_cut, dim3(nframes), dim3(256), 0, s, a, d_kept);
   HIP_TRY(hipGetLastError());

@@ -1262,7 +1262,14 @@ struct StereoArgs {
   int            cap;
   const int *    countsL, *countsR;
   long long      img0StrideL, img0StrideR, pyrBytes;
+  // row index of the right keypoints (k_stereo_rows): rowIdx[rowStart[y] .. rowStart[y + 1]) = the right keypoints with (int)pt.y == y;
+  // a left keypoint on row v only has to look at rows v - rowBand .. v + rowBand (rowBand >= 2 * the largest scale factor + 1 covers
+  // every iR whose band [floor(y - r), ceil(y + r)] holds v).  NULL = scan all right keypoints.
+  int *rowStart, *rowIdx;
+  int  rowBand;
 };
+
+constexpr int kStereoMaxRows = 4096;  // image rows the row index is built for (taller images scan all right keypoints)
 
 __device__ __forceinline__ StereoArgs stereo_view(const StereoArgs& a, int f) {
   if (a.cap <= 0) return a;
@@ -1273,7 +1280,47 @@ __device__ __forceinline__ StereoArgs stereo_view(const StereoArgs& a, int f) {
   v.pyrL0 = a.pyrL0 + f * a.img0StrideL, v.pyrR0 = a.pyrR0 + f * a.img0StrideR;
   v.pyrL = a.pyrL + f * a.pyrBytes, v.pyrR = a.pyrR + f * a.pyrBytes;
   v.uRight = a.uRight + fc, v.depth = a.depth + fc, v.sad = a.sad + fc;
+  if (a.rowStart) v.rowStart = a.rowStart + (long long)f * (a.nrows + 1), v.rowIdx = a.rowIdx + fc;
   return v;
+}
+
+// vRowIndices of Frame::ComputeStereoMatches (src/Frame.cc:955-973) as a counting sort of the right keypoints by image row: one
+// workgroup per frame.  The per-row LISTS of the reference (every keypoint entered in all rows of its band) are not built; the
+// matcher walks the rows of the band instead and applies the reference's own band test to every keypoint it finds there.
+__global__ __launch_bounds__(256) void k_stereo_rows(StereoArgs a0) {
+  __shared__ int hist[kStereoMaxRows + 1];
+  __shared__ int part[256];
+  const StereoArgs a   = stereo_view(a0, blockIdx.x);
+  const int        tid = threadIdx.x, nrows = a.nrows;
+  for (int i = tid; i <= nrows; i += 256) hist[i] = 0;
+  __syncthreads();
+  for (int i = tid; i < a.nr; i += 256) atomicAdd(&hist[min(max((int)a.kr[i].y, 0), nrows - 1)], 1);
+  __syncthreads();
+  // exclusive scan over the rows: per-thread chunks, then the chunk totals
+  const int per = (nrows + 255) / 256, lo = min(tid * per, nrows), hi = min(lo + per, nrows);
+  int       sum = 0;
+  for (int i = lo; i < hi; i++) sum += hist[i];
+  part[tid] = sum;
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    for (int i = 0; i < 256; i++) {
+      const int t = part[i];
+      part[i]     = run;
+      run += t;
+    }
+  }
+  __syncthreads();
+  int run = part[tid];
+  for (int i = lo; i < hi; i++) {
+    const int t   = hist[i];
+    hist[i]       = run;  // becomes the fill cursor of the row
+    a.rowStart[i] = run;
+    run += t;
+  }
+  if (tid == 255) a.rowStart[nrows] = a.nr;
+  __syncthreads();
+  for (int i = tid; i < a.nr; i += 256) a.rowIdx[atomicAdd(&hist[min(max((int)a.kr[i].y, 0), nrows - 1)], 1)] = i;
 }
 
 __global__ __launch_bounds__(256) void k_stereo_match(StereoArgs a0, FrameGeom g) {
@@ -1291,7 +1338,15 @@ __global__ __launch_bounds__(256) void k_stereo_match(StereoArgs a0, FrameGeom g
   uint32_t    best = 0xffffffffu;
   if (!(maxU < 0)) {
     const uint4 a0 = *reinterpret_cast<const uint4*>(a.dl + (size_t)iL * 32), a1 = *reinterpret_cast<const uint4*>(a.dl + (size_t)iL * 32 + 16);
-    for (int iR = lane; iR < a.nr; iR += 64) {
+    const bool byRow = a.rowStart != nullptr;
+    int        pLo = 0, pHi = a.nr;
+    if (byRow) {
+      const bool in = rowL >= 0 && rowL < a.nrows;
+      pLo           = in ? a.rowStart[max(rowL - a.rowBand, 0)] : 0;
+      pHi           = in ? a.rowStart[min(rowL + a.rowBand + 1, a.nrows)] : 0;
+    }
+    for (int p = pLo + lane; p < pHi; p += 64) {
+      const int   iR   = byRow ? a.rowIdx[p] : p;
       const KpRec kpR  = a.kr[iR];
       const float r    = 2.0f * g.lv[kpR.octave].scale;
       const int   maxr = (int)ceilf(kpR.y + r), minr = (int)floorf(kpR.y - r);
