@@ -150,7 +150,10 @@ struct orbx_extractor {
   int             lastB    = 0;
   orbx::Bufs      bufs{};
   DevBuf<uint8_t> dPyr, dBlur, dNCh, dStage, dRaw, dDescOut, dOutBlock;
-  DevBuf<int>     dStereoSad, dStereoRowStart, dStereoRowIdx;
+  DevBuf<int>     dStereoSad, dStereoRowStart, dStereoRowIdx, sSad, sKept, sRow, sRidx;
+  DevBuf<orbx::KpRec> sKl, sKr;
+  DevBuf<uint8_t> sDl, sDr;
+  DevBuf<float>   sU, sDepth;
   DevBuf<int2>    dXtab, dYtab;
   DevBuf<int4>    dCellDesc;
   DevBuf<long long> dDbgT;
@@ -869,7 +872,7 @@ void orbx_destroy(orbx_t* h) {
   if (h->evValid)
     for (auto& slot : h->ev)
       for (auto& e : slot) hipEventDestroy(e);
-  h->dPyr.release(), h->dBlur.release(), h->dStereoSad.release(), h->dStereoRowStart.release(), h->dStereoRowIdx.release(), h->dRaw.release(), h->dPre.release(), h->dPreX.release(), h->dPreY.release(), h->dStage.release(), h->dDescOut.release(), h->dOutBlock.release(), h->dXtab.release(), h->dYtab.release();
+  h->dPyr.release(), h->dBlur.release(), h->dStereoSad.release(), h->dStereoRowStart.release(), h->dStereoRowIdx.release(), h->sSad.release(), h->sKept.release(), h->sRow.release(), h->sRidx.release(), h->sKl.release(), h->sKr.release(), h->sDl.release(), h->sDr.release(), h->sU.release(), h->sDepth.release(), h->dRaw.release(), h->dPre.release(), h->dPreX.release(), h->dPreY.release(), h->dStage.release(), h->dDescOut.release(), h->dOutBlock.release(), h->dXtab.release(), h->dYtab.release();
   h->dTiles.release(), h->dTileOrder.release(), h->dCellDesc.release(), h->dCellOrder.release(), h->dCellSlot.release(), h->dCellCount.release(), h->dNodeOf.release(), h->dCellOffs.release();
   h->dD.release(), h->dDIndex.release(), h->dNCh.release(), h->dPushOff.release(), h->dMultiOff.release();
   h->dKeptRank.release(), h->dVA.release(), h->dVB.release(), h->dCandCount.release(), h->dLvlCount.release(), h->dOutIdx.release();
@@ -1483,10 +1486,11 @@ int orbx_stereo_matches(orbx_t* left, orbx_t* right, const orbx_keypoint_t* kl, 
   HIP_TRY(hipSetDevice(left->device));
   HIP_TRY(hipStreamSynchronize(right->stream));
   hipStream_t      s = left->stream;
-  DevBuf<KpRec>    dkl, dkr;
-  DevBuf<uint8_t>  ddl, ddr;
-  DevBuf<float>    du, dd;
-  DevBuf<int>      dsad, dkept, drow, dridx;
+  // staging of the host-pointer form lives in the left handle (grow-only): ten hipMalloc / hipFree pairs per call were most of its latency
+  DevBuf<KpRec>&   dkl = left->sKl, &dkr = left->sKr;
+  DevBuf<uint8_t>& ddl = left->sDl, &ddr = left->sDr;
+  DevBuf<float>&   du = left->sU, &dd = left->sDepth;
+  DevBuf<int>&     dsad = left->sSad, &dkept = left->sKept, &drow = left->sRow, &dridx = left->sRidx;
   const bool       byRow = left->geom.rows <= kStereoMaxRows && nr > 0;
   if (dkl.ensure(nl) || dkr.ensure(nr + 1) || ddl.ensure((size_t)nl * 32) || ddr.ensure((size_t)nr * 32 + 32) || du.ensure(nl) || dd.ensure(nl) ||
       dsad.ensure(nl) || dkept.ensure(1) || (byRow && (drow.ensure(left->geom.rows + 2) || dridx.ensure(nr + 1))))
@@ -1519,7 +1523,6 @@ int orbx_stereo_matches(orbx_t* left, orbx_t* right, const orbx_keypoint_t* kl, 
   HIP_TRY(hipMemcpyAsync(depth, dd.p, (size_t)nl * 4, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipMemcpyAsync(&kept, dkept.p, 4, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
-  dkl.release(), dkr.release(), ddl.release(), ddr.release(), du.release(), dd.release(), dsad.release(), dkept.release(), drow.release(), dridx.release();
   return kept;
 }
 
