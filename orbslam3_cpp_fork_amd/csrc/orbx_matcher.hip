@@ -862,6 +862,7 @@ struct ProjArgs {
   int                    n1, n2, ng;
   const int*             g_idx;
   const uint8_t *        g_cx, *g_cy;
+  const int*             colStart;  // [kGridCols + 1]: first list position of grid column c (the list is sorted by cell = cx * rows + cy); NULL = scan the whole list
   const float*           sf;
   float                  th, mbf, minX, minY, gwInv, ghInv;
   int                    dir, thDist, check_ori;
@@ -902,6 +903,7 @@ __device__ __forceinline__ ProjArgs proj_view(const ProjArgs& a, int p) {
   v.occupied = a.occupied ? a.occupied + pc : nullptr;
   v.n1 = a.counts[2 * fl], v.n2 = a.counts[2 * fc], v.ng = a.ngOf[fc];
   v.g_idx = a.g_idx + cc, v.g_cx = a.g_cx + cc, v.g_cy = a.g_cy + cc;
+  v.colStart = a.colStart ? a.colStart + (size_t)fc * (kGridCols + 1) : nullptr;
   v.topk = a.topk + pc * kTopK, v.nvalid = a.nvalid + pc, v.m12 = a.m12 + pc, v.m21 = a.m21 + pc, v.binOf = a.binOf + pc;
   v.nmatches = a.nmatches + p;
   return v;
@@ -936,6 +938,12 @@ __device__ __forceinline__ ProjQuery proj_query(const ProjArgs& a, int i) {
   q.y1    = min(kGridRows - 1, (int)ceilf((q.v - a.minY + q.r) * a.ghInv));
   q.empty = (q.x0 >= kGridCols) || (q.x1 < 0) || (q.y0 >= kGridRows) || (q.y1 < 0);
   return q;
+}
+
+// list positions that can hold a candidate of query q: the grid columns x0 .. x1 of its window are one contiguous run of the list
+__device__ __forceinline__ void proj_range(const ProjArgs& a, const ProjQuery& q, int* lo, int* hi) {
+  *lo = a.colStart ? a.colStart[q.x0] : 0;
+  *hi = a.colStart ? a.colStart[q.x1 + 1] : a.ng;
 }
 
 // candidate at grid-scan position pos for query q: the feature index, or -1 (outside the window / level range / stereo
@@ -986,8 +994,10 @@ __global__ __launch_bounds__(256) void k_proj_topk(ProjArgs a0) {
     const ProjQuery q = proj_query(a, i1);
     if (!q.empty) {
       const ProjArgs& ar = a;
+      int             pLo, pHi;
+      proj_range(a, q, &pLo, &pHi);
       wave_topk(
-          a.d1 + (size_t)i1 * 32, a.d2, 0, a.ng, [&ar, &q](int pos) { return proj_candidate(ar, q, pos); },
+          a.d1 + (size_t)i1 * 32, a.d2, pLo, pHi, [&ar, &q](int pos) { return proj_candidate(ar, q, pos); },
           [thd = ar.mode == 1 ? ar.dstar - 1 : ar.thDist](int, int d) { return d <= thd; }, out, &nv);  // mode 0: only "bestDist <= TH_HIGH" can match (:1788)
     }
   }
@@ -1021,9 +1031,11 @@ __global__ __launch_bounds__(256) void k_proj_take_best(ProjArgs a) {
 // One workgroup per frame; keys cell << 16 | index bitonic-sorted in LDS (NP = power of two >= cap, <= 8192).
 __global__ __launch_bounds__(256) void k_assign_grid(const orbx_keypoint_t* __restrict__ kps, const int* __restrict__ counts, int cap, int NP,
                                                      float minX, float minY, float gwInv, float ghInv, int* __restrict__ g_idx,
-                                                     uint8_t* __restrict__ g_cx, uint8_t* __restrict__ g_cy, int* __restrict__ ngOf) {
+                                                     uint8_t* __restrict__ g_cx, uint8_t* __restrict__ g_cy, int* __restrict__ ngOf,
+                                                     int* __restrict__ colStart) {
   extern __shared__ uint32_t gridKeys[];
   __shared__ int             sCount;
+  __shared__ int             sCol[kGridCols + 1];
   const int                  f = blockIdx.x, tid = threadIdx.x;
   const int                  n = min(counts ? counts[2 * f] : cap, NP);
   if (tid == 0) sCount = 0;
@@ -1059,6 +1071,16 @@ __global__ __launch_bounds__(256) void k_assign_grid(const orbx_keypoint_t* __re
     g_cy[(size_t)f * cap + p]  = (uint8_t)(cell % kGridRows);
   }
   if (tid == 0) ngOf[f] = ng;
+  if (colStart) {  // first list position of every grid column (the list is sorted by cell): a window search only walks its columns' run
+    for (int c = tid; c <= kGridCols; c += 256) sCol[c] = ng;
+    __syncthreads();
+    for (int p = tid; p < ng; p += 256) atomicMin(&sCol[(int)(gridKeys[p] >> 16) / kGridRows], p);
+    __syncthreads();
+    if (tid == 0)
+      for (int c = kGridCols - 1; c >= 0; c--) sCol[c] = min(sCol[c], sCol[c + 1]);
+    __syncthreads();
+    for (int c = tid; c <= kGridCols; c += 256) colStart[(size_t)f * (kGridCols + 1) + c] = sCol[c];
+  }
 }
 
 // The reference walks the points one by one; a point's choice only depends on which features EARLIER points took.  The wave
@@ -1166,9 +1188,10 @@ __global__ __launch_bounds__(64) void k_proj_resolve(ProjArgs a0) {
         const ProjArgs& ar = a;
         const uint32_t* cl = claimed;
         uint32_t        out[kTopK];
-        int             nv2;
+        int             nv2, pLo, pHi;
+        proj_range(a, q, &pLo, &pHi);
         wave_topk(
-            a.d1 + (size_t)iq * 32, a.d2, 0, a.ng,
+            a.d1 + (size_t)iq * 32, a.d2, pLo, pHi,
             [&ar, &q, cl](int pos) {
               const int i2 = proj_candidate(ar, q, pos);
               return (i2 >= 0 && (cl[i2 >> 5] & (1u << (i2 & 31)))) ? -1 : i2;
@@ -1312,7 +1335,8 @@ struct orbm_matcher {
   hipStream_t stream = nullptr;
   Arena       in, out;
   DBuf<uint8_t>         dq, dt, dqv, dtv, gcx, gcy;
-  DBuf<int>             qoff, qidx, toff, tidx, nvalid, binOf, mq, mt, nm, gidx, dbg;
+  DBuf<int>             qoff, qidx, toff, tidx, nvalid, binOf, mq, mt, nm, gidx, dbg, colStart;
+  int*                  colStartOut = nullptr;  // set while the internal grid build runs (orbm_search_by_projection_batch_device)
   bool                  dbgOn = false;
   DBuf<float>           qa, ta, prev;
   DBuf<uint32_t>        topk;
@@ -1991,7 +2015,7 @@ static int proj_single(orbm_t* h, int mode, const float* inv_sigma2, const float
       }
   }
   hipStream_t  s  = h->stream;
-  const size_t inBytes = (size_t)n1 * (32 + 8 + 4 + 4 + 4 + 4 + 1) + (size_t)n2 * (32 + sizeof(orbx_keypoint_t) + 4 + 1) + (size_t)ng * 6 + (size_t)2 * nlevels * 4 + 16 * 24;
+  const size_t inBytes = (size_t)n1 * (32 + 8 + 4 + 4 + 4 + 4 + 1) + (size_t)n2 * (32 + sizeof(orbx_keypoint_t) + 4 + 1) + (size_t)ng * 6 + (size_t)2 * nlevels * 4 + (kGridCols + 1) * 4 + 16 * 25;
   const size_t outBytes = (size_t)(n1 + n2 + 4) * 4 + 64;
   if (h->in.reserve(inBytes) || h->out.reserve(outBytes) || h->topk.ensure((size_t)(n1 + 1) * kTopK) || h->nvalid.ensure(n1 + 1) ||
       h->binOf.ensure(n1 + 1))
@@ -2001,6 +2025,11 @@ static int proj_single(orbm_t* h, int mode, const float* inv_sigma2, const float
   Arena& in = h->in;
   a.d1 = in.put(last_desc, (size_t)n1 * 32), a.d2 = in.put(cur_desc, (size_t)n2 * 32), a.kp2 = in.put(cur_kp, n2);
   a.g_idx = in.put(gidx.data(), ng), a.g_cx = in.put(gcx.data(), ng), a.g_cy = in.put(gcy.data(), ng);
+  {
+    int cs[kGridCols + 1];
+    for (int c = 0; c <= kGridCols; c++) cs[c] = cellCount[c * kGridRows];
+    a.colStart = in.put(cs, kGridCols + 1);
+  }
   a.uv = in.put(last_uv, (size_t)2 * n1), a.angle1 = last_angle ? in.put(last_angle, n1) : nullptr, a.invz = last_invz ? in.put(last_invz, n1) : nullptr;
   a.radius1 = radius1 ? in.put(radius1, n1) : nullptr, a.mode = mode, a.ratio = ratio;
   a.invSigma2 = inv_sigma2 ? in.put(inv_sigma2, nlevels) : nullptr;
@@ -2081,9 +2110,10 @@ __device__ __forceinline__ void tc_pick(const ProjArgs& a, int i, const uint32_t
   const ProjQuery q  = proj_query(a, i);
   const ProjArgs& ar = a;
   uint32_t        out[kTopK];
-  int             nv2;
+  int             nv2, pLo, pHi;
+  proj_range(a, q, &pLo, &pHi);
   wave_topk(
-      a.d1 + (size_t)i * 32, a.d2, 0, a.ng,
+      a.d1 + (size_t)i * 32, a.d2, pLo, pHi,
       [&ar, &q, occ, occBase](int pos) {
         const int i2 = proj_candidate(ar, q, pos);
         return (i2 >= 0 && occ[occBase + i2]) ? -1 : i2;
@@ -2219,6 +2249,7 @@ int orbm_search_by_projection_map_two_cameras(orbm_t* h, const uint8_t* mp_desc,
     std::vector<int>     gidx;
     std::vector<uint8_t> gcx, gcy;
     int                  ng = 0;
+    int                  colStart[kGridCols + 1];
   } grids[2];
   for (int cam = 0; cam < 2; cam++) {
     const orbx_keypoint_t* kp = cur_kp + (cam ? nleft : 0);
@@ -2233,6 +2264,7 @@ int orbm_search_by_projection_map_two_cameras(orbm_t* h, const uint8_t* mp_desc,
     for (int c = 0; c < kGridCols * kGridRows; c++) cellCount[c + 1] += cellCount[c];
     CamGrid& G = grids[cam];
     G.ng       = cellCount[kGridCols * kGridRows];
+    for (int c = 0; c <= kGridCols; c++) G.colStart[c] = cellCount[c * kGridRows];
     G.gidx.resize(G.ng + 1), G.gcx.resize(G.ng + 1), G.gcy.resize(G.ng + 1);
     std::vector<int> fill(cellCount.begin(), cellCount.end() - 1);
     for (int i = 0; i < m; i++)
@@ -2244,7 +2276,7 @@ int orbm_search_by_projection_map_two_cameras(orbm_t* h, const uint8_t* mp_desc,
       }
   }
   hipStream_t  s       = h->stream;
-  const size_t inBytes = (size_t)n1 * (32 + 2 * (8 + 4 + 4 + 1)) + (size_t)n * (32 + sizeof(orbx_keypoint_t) + 1 + 4 + 6) + (size_t)nlevels * 4 + 16 * 32;
+  const size_t inBytes = (size_t)n1 * (32 + 2 * (8 + 4 + 4 + 1)) + (size_t)n * (32 + sizeof(orbx_keypoint_t) + 1 + 4 + 6) + (size_t)nlevels * 4 + 2 * (kGridCols + 1) * 4 + 16 * 34;
   if (h->in.reserve(inBytes) || h->out.reserve((size_t)(n + 4) * 4 + 64) || h->topk.ensure((size_t)(2 * n1 + 2) * kTopK) || h->nvalid.ensure(2 * n1 + 2)) return -3;
   Arena&        in = h->in;
   MapTwoCamArgs a;
@@ -2262,6 +2294,7 @@ int orbm_search_by_projection_map_two_cameras(orbm_t* h, const uint8_t* mp_desc,
     v.d1 = dMp, v.d2 = dDesc + (size_t)(cam ? nleft : 0) * 32, v.kp2 = dKp + (cam ? nleft : 0);
     v.occupied = dOcc ? dOcc + (cam ? nleft : 0) : nullptr;
     v.g_idx = in.put(G.gidx.data(), G.ng), v.g_cx = in.put(G.gcx.data(), G.ng), v.g_cy = in.put(G.gcy.data(), G.ng);
+    v.colStart = in.put(G.colStart, kGridCols + 1);
     v.uv = in.put(cam ? uv_r : uv_l, (size_t)2 * n1), v.radius1 = in.put(cam ? radius_r : radius_l, n1), v.oct1 = in.put(cam ? level_r : level_l, n1);
     v.valid1 = in.put(cam ? valid_r : valid_l, n1);
     v.mode = 1, v.ratio = ratio, v.dstar = D, v.sf = dSf;
@@ -2479,7 +2512,7 @@ int orbm_assign_features_to_grid_device(orbm_t* h, const orbx_keypoint_t* d_kps_
   while (NP < cap) NP <<= 1;
   const float gwInv = static_cast<float>(kGridCols) / (max_x - min_x), ghInv = static_cast<float>(kGridRows) / (max_y - min_y);
   hipLaunchKernelGGL(k_assign_grid, dim3(nframes), dim3(256), (size_t)NP * 4, stream ? (hipStream_t)stream : h->stream, d_kps_un, d_counts, cap, NP,
-                     min_x, min_y, gwInv, ghInv, d_g_idx, d_g_cx, d_g_cy, d_ng);
+                     min_x, min_y, gwInv, ghInv, d_g_idx, d_g_cx, d_g_cy, d_ng, h->colStartOut);
   HIP_TRYM(hipGetLastError());
   return 0;
 }
@@ -2507,10 +2540,12 @@ int orbm_search_by_projection_batch_device(orbm_t* h, int npairs, const int* d_p
   hipStream_t  s  = stream ? (hipStream_t)stream : h->stream;
   const size_t fc = (size_t)nframes * cap, pc = (size_t)npairs * cap;
   if (h->gidx.ensure(fc) || h->gcx.ensure(fc) || h->gcy.ensure(fc) || h->qoff.ensure(nframes + 1) || h->ta.ensure(64) ||
-      h->topk.ensure(pc * kTopK) || h->nvalid.ensure(pc) || h->binOf.ensure(pc))
+      h->topk.ensure(pc * kTopK) || h->nvalid.ensure(pc) || h->binOf.ensure(pc) || h->colStart.ensure((size_t)nframes * (kGridCols + 1)))
     return -3;
+  h->colStartOut = h->colStart.p;  // the internal grid build also writes the per-column starts
   int rc = orbm_assign_features_to_grid_device(h, d_kps_un, d_counts, nframes, cap, min_x, max_x, min_y, max_y, h->gidx.p, h->gcx.p, h->gcy.p,
                                                h->qoff.p, s);
+  h->colStartOut = nullptr;
   if (rc) return rc;
   HIP_TRYM(hipMemcpyAsync(h->ta.p, scale_factors, (size_t)nlevels * 4, hipMemcpyHostToDevice, s));
   ProjArgs a;
@@ -2518,6 +2553,7 @@ int orbm_search_by_projection_batch_device(orbm_t* h, int npairs, const int* d_p
   a.pairs = d_pairs, a.counts = d_counts, a.ngOf = h->qoff.p, a.cap = cap, a.hasLastDesc = d_last_desc ? 1 : 0;
   a.d1 = d_last_desc, a.d2 = d_desc, a.kp2 = d_kps_un, a.uv = d_last_uv, a.invz = d_last_invz, a.valid1 = d_last_valid;
   a.uRight = d_u_right, a.occupied = d_occupied, a.g_idx = h->gidx.p, a.g_cx = h->gcx.p, a.g_cy = h->gcy.p, a.sf = h->ta.p;
+  a.colStart = h->colStart.p;
   a.th = th, a.mbf = mbf, a.minX = min_x, a.minY = min_y, a.gwInv = static_cast<float>(kGridCols) / (max_x - min_x);
   a.ghInv = static_cast<float>(kGridRows) / (max_y - min_y), a.dir = dir, a.thDist = th_dist, a.check_ori = check_ori;
   a.topk = h->topk.p, a.nvalid = h->nvalid.p, a.binOf = h->binOf.p, a.m12 = d_cur_of_last, a.m21 = d_last_of_cur, a.nmatches = d_nmatches;
