@@ -43,6 +43,7 @@ class ORBextractor {
     if (cap < 0) throw std::runtime_error(std::string("orbx_max_keypoints: ") + orbx_last_error());
     kp_.resize(cap);
     desc_.resize((size_t)cap * 32);
+    if (mbDownloadPyramid != downloading_) orbx_set_pyramid_download(h_, mbDownloadPyramid ? 1 : 0), downloading_ = mbDownloadPyramid;
     int       n  = 0;
     const int rc = orbx_extract(h_, image.ptr(0), image.rows, image.cols, (size_t)image.step, vLappingArea.at(0), vLappingArea.at(1), kp_.data(),
                                 desc_.data(), cap, &n);
@@ -57,12 +58,21 @@ class ORBextractor {
       for (int i = 0; i < n; i++) std::memcpy(descriptors.ptr(i), desc_.data() + (size_t)i * 32, 32);
     }
     if (mbDownloadPyramid) {  // Frame::ComputeStereoMatches reads mvImagePyramid (src/Frame.cc:950, 1039-1058)
+      // levels >= 1 already lie in pinned host memory (orbx_set_pyramid_download: they came home behind the records); level 0 is the
+      // device's level 0 as well, so a fused input resize (orbx_set_input_resize) shows up here as it does in the reference
       for (int l = 0; l < nlevels; l++) {
         int r = 0, c = 0;
-        orbx_pyramid_level(h_, 0, l, nullptr, 0, &r, &c);
+        if (orbx_pyramid_level(h_, 0, l, nullptr, 0, &r, &c) != 0) throw std::runtime_error(std::string("orbx_pyramid_level: ") + orbx_last_error());
+        if (l == 0 && r == image.rows && c == image.cols) {  // no resize: level 0 IS the input image
+          mvImagePyramid[0] = image.clone();
+          continue;
+        }
         mvImagePyramid[l].create(r, c, orbx_cv::CV_8U);
-        orbx_pyramid_level(h_, 0, l, mvImagePyramid[l].ptr(0), (size_t)mvImagePyramid[l].step, &r, &c);
+        if (orbx_pyramid_level(h_, 0, l, mvImagePyramid[l].ptr(0), (size_t)mvImagePyramid[l].step, &r, &c) != 0)
+          throw std::runtime_error(std::string("orbx_pyramid_level: ") + orbx_last_error());
       }
+    } else {
+      for (auto& m : mvImagePyramid) m.release();
     }
     return rc;
   }
@@ -74,11 +84,12 @@ class ORBextractor {
   std::vector<float> inline GetScaleSigmaSquares() { return mvLevelSigma2; }
   std::vector<float> inline GetInverseScaleSigmaSquares() { return mvInvLevelSigma2; }
 
-  std::vector<orbx_cv::Mat> mvImagePyramid;            // host copies of the device pyramid of the last call
-  // Off by default: only Frame::ComputeStereoMatches reads mvImagePyramid (src/Frame.cc:950, 1039-1058), and with orbx_stereo_matches
-  // not even the stereo path needs host copies.  A caller that keeps the reference's host-side ComputeStereoMatches sets it to true
-  // (8 synchronous D2H copies per call).
-  bool                      mbDownloadPyramid = false;
+  std::vector<orbx_cv::Mat> mvImagePyramid;            // host copies of the device pyramid of the last call (reference include/ORBextractor.h:87)
+  // ON by default: an UNCHANGED Frame::ComputeStereoMatches reads mvImagePyramid (src/Frame.cc:950, 1039-1058) and must find the levels
+  // there.  The levels ride home inside the call (orbx_set_pyramid_download), so the price is one more copy in the queue, not a round
+  // trip per level.  A host that does not read the pyramid (monocular tracking; stereo through orbx_stereo_matches, which works on the
+  // device-resident levels) opts out with `extractor->mbDownloadPyramid = false;` -- the one line INTEGRATION.md section 1 lists as optional.
+  bool                      mbDownloadPyramid = true;
   orbx_t*                   handle() { return h_; }
 
  protected:
@@ -92,6 +103,7 @@ class ORBextractor {
 
  private:
   orbx_t*                      h_ = nullptr;
+  bool                         downloading_ = false;  // what orbx_set_pyramid_download was last told
   std::vector<orbx_keypoint_t> kp_;
   std::vector<uint8_t>         desc_;
 };

@@ -150,6 +150,13 @@ int  orbx_gather(orbx_comm_t* c, const orbx_keypoint_t* d_kps, const uint8_t* d_
  * dst may be NULL to query the size. */
 int orbx_pyramid_level(orbx_t* h, int frame, int level, uint8_t* dst, size_t dst_step, int* rows, int* cols);
 
+/* enable != 0: every orbx_extract also brings levels >= 1 of its pyramid to pinned host memory, behind the records and before the
+ * call's one synchronisation (one more copy in the same queue instead of a blocking round trip per level); orbx_pyramid_level(h, 0,
+ * level >= 1, ...) is then a host copy.  Level 0 is the caller's own image (or, with orbx_set_input_resize, fetched on demand).
+ * This is what the adaptor's mbDownloadPyramid (default true: an unchanged Frame::ComputeStereoMatches reads mvImagePyramid,
+ * src/Frame.cc:950, 1039-1058) turns on.  Off by default at this level.  Returns 0, -2 for a null handle. */
+int orbx_set_pyramid_download(orbx_t* h, int enable);
+
 /* Frame::ComputeStereoMatches (reference src/Frame.cc:944-1113) on the device-resident pyramids of two extractors
  * that have just run orbx_extract on the left / right image (same size, same device): row-band candidate search,
  * best Hamming below TH_HIGH, 11 x 11 SAD over +-5 px on the keypoint's pyramid level, parabola sub-pixel fit,
@@ -195,6 +202,9 @@ int orbx_debug_calib_read(orbx_t* h, long long nbytes, int width);
  * orbx_debug_valu_calib_name(op) names the instruction (NULL past the last one).  Tuning hook: tools/valu_calibrate.py. */
 int         orbx_debug_valu_calib(int op, int waves_per_simd, int iters, double out[3]);
 const char* orbx_debug_valu_calib_name(int op);
+/* LDS read issue rate: ds_read_b32 (width 4) / ds_read_b64 (width 8) at lane * width + off; off != 0 = not naturally aligned.
+ * out = {ns of the launch, median shader cycles per wave, LDS read instructions per wave, lanes that read wrong bytes}. */
+int orbx_debug_lds_calib(int width, int off, int waves_per_simd, int iters, double out[4]);
 /* Device run of DistributeOctTree alone on caller-supplied candidates (host arrays). */
 int orbx_debug_octree_device(orbx_t* h, const uint32_t* cand, int n, int W, int H, int N, uint32_t* out, int* out_count);
 

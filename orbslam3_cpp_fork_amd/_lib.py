@@ -56,6 +56,7 @@ SIGNATURES = {
     "orbx_stereo_matches": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _f, _f, _vp, _vp]),
     "orbx_stereo_matches_batch_device": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _vp, _vp, _vp, _vp]),
     "orbx_pyramid_level": (_i, [_vp, _i, _i, _vp, _sz, _ip, _ip]),
+    "orbx_set_pyramid_download": (_i, [_vp, _i]),
     "orbx_set_profiling": (None, [_vp, _i]),
     "orbx_get_stage_ms": (_i, [_vp, _vp]),
     "orbx_debug_blurred_level": (_i, [_vp, _i, _i, _vp, _sz, _ip, _ip]),
@@ -65,6 +66,7 @@ SIGNATURES = {
     "orbx_debug_calib_read": (_i, [_vp, C.c_longlong, _i]),
     "orbx_debug_valu_calib": (_i, [_i, _i, _i, _vp]),
     "orbx_debug_valu_calib_name": (C.c_char_p, [_i]),
+    "orbx_debug_lds_calib": (_i, [_i, _i, _i, _i, _vp]),
     "orbx_debug_octree_device": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _ip]),
     "orbm_create": (_i, [C.POINTER(_vp), _i]),
     "orbm_destroy": (None, [_vp]),

@@ -18,24 +18,47 @@ HIPFLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "
 CXXFLAGS = ["-O2", "-ffp-contract=off", "-std=c++17", "-fPIC", "-Wall"]
 
 
+STAMP = os.path.join(HERE, "_build", "liborbx.sha256")
+
+
+def _tuning():
+    """ORBX_BUILD_TUNING=1 compiles the tuning hooks in (-DORBX_TUNING: ORBX_DBG_SKIP_FAST phase ablation, ORBX_DBG_OCT stamps)."""
+    return os.environ.get("ORBX_BUILD_TUNING", "") not in ("", "0")
+
+
+def source_digest():
+    """sha256 over every source, header, this recipe and the flags: what the in-tree liborbx.so must have been built from."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in sorted(HIP_SOURCES + HOST_SOURCES + HEADERS):
+        path = os.path.join(CSRC, f)
+        if os.path.exists(path):
+            h.update(f.encode() + b"\0" + open(path, "rb").read())
+    h.update(open(os.path.abspath(__file__), "rb").read())
+    h.update(repr((HIPFLAGS, CXXFLAGS, _tuning())).encode())
+    return h.hexdigest()
+
+
 def _stale():
-    if not os.path.exists(OUT):
+    """By content, not by mtime: the .so is git-ignored but travels with the snapshot, and a checkout or copy can leave a source file older
+    than a library that was built from something else."""
+    if not os.path.exists(OUT) or not os.path.exists(STAMP):
         return True
-    t = os.path.getmtime(OUT)
-    deps = [os.path.join(CSRC, f) for f in HIP_SOURCES + HOST_SOURCES + HEADERS] + [os.path.abspath(__file__)]
-    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+    return open(STAMP).read().strip() != source_digest()
 
 
 def build(force=False, verbose=False):
     if not force and not _stale():
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    extra = ["-DORBX_TUNING"] if _tuning() else []
     bdir = os.path.join(HERE, "_build")
     os.makedirs(bdir, exist_ok=True)
     objs = []
     for src in HOST_SOURCES:
         obj = os.path.join(bdir, os.path.splitext(src)[0] + ".o")
-        cmd = ["g++"] + CXXFLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = ["g++"] + CXXFLAGS + extra + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
@@ -45,7 +68,7 @@ def build(force=False, verbose=False):
         if not os.path.exists(path):
             continue
         obj = os.path.join(bdir, os.path.splitext(src)[0] + ".o")
-        cmd = [hipcc] + HIPFLAGS + ["-c", path, "-o", obj]
+        cmd = [hipcc] + HIPFLAGS + extra + ["-c", path, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
@@ -88,6 +111,8 @@ def build(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    with open(STAMP, "w") as f:
+        f.write(source_digest() + "\n")
     return OUT
 
 

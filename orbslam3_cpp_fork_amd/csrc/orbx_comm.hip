@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -18,6 +19,7 @@
 #include "../../include/orbx.h"
 
 extern "C" void orbx_internal_set_error(const char* s);
+extern "C" int  orbx_internal_runtime_down(void);
 
 namespace {
 
@@ -39,14 +41,35 @@ std::mutex g_rcclMutex;
 bool load_rccl() {
   std::lock_guard<std::mutex> lock(g_rcclMutex);
   if (g_rccl.lib) return true;
-  const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
+  // The copy a process already has mapped comes first (PyTorch bundles one under its soname librccl.so.1: a second RCCL beside it would
+  // bring a second set of communicator state), then the loader path, then /opt/rocm.  ORBX_RCCL_LIBRARY names the one library to try
+  // instead (deployments with a private RCCL; tests/test_abi_and_hostmodel.py uses it to reach the failure path).
+  const char* forced  = getenv("ORBX_RCCL_LIBRARY");
+  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
   void*       lib     = nullptr;
-  for (const char* n : names) {
-    lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-    if (lib) break;
+  std::string why;
+  if (forced && *forced) {
+    lib = dlopen(forced, RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) {
+      const char* e = dlerror();  // one call: dlerror() clears the message it returns
+      why = e ? e : "";
+    }
+  } else {
+    for (const char* n : names) {
+      lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
+      if (lib) break;
+    }
+    for (const char* n : names) {
+      if (lib) break;
+      lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+      if (!lib) {
+        const char* e = dlerror();
+        if (e) why = e;
+      }
+    }
   }
   if (!lib) {
-    orbx_internal_set_error((std::string("orbx_comm: cannot open librccl.so: ") + (dlerror() ? dlerror() : "")).c_str());
+    orbx_internal_set_error((std::string("orbx_comm: cannot open librccl.so: ") + why).c_str());
     return false;
   }
   Rccl r;
@@ -126,7 +149,7 @@ int orbx_comm_create(orbx_comm_t** out, int device_id, int rank, int nranks, con
 
 void orbx_comm_destroy(orbx_comm_t* c) {
   if (!c) return;
-  if (c->comm && g_rccl.commDestroy) {
+  if (c->comm && g_rccl.commDestroy && !orbx_internal_runtime_down()) {
     hipSetDevice(c->device);
     g_rccl.commDestroy(c->comm);
   }

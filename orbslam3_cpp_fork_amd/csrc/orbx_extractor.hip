@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <mutex>
 
 #include <algorithm>
 #include <cmath>
@@ -43,7 +44,51 @@ const signed char kPatternHost[1024] = {
 #include "orb_pattern.inc"
 };
 
-static std::atomic<unsigned long long> g_allocEpoch{0};  // bumped by every (re)allocation of a device buffer of any handle (handles may live on different host threads)
+// A recorded hipGraph of orbx_extract holds device addresses: a reallocation of one of the handle's buffers retires it (GraphKey::epoch).
+// The counter is the HANDLE's (EpochScope names it for the duration of an entry point); allocations made outside any scope -- none today
+// -- fall back to a process-wide counter that is part of every key, so a forgotten scope costs replays, never correctness.
+static std::atomic<unsigned long long> g_allocEpochFallback{0};
+thread_local unsigned long long*       t_allocEpoch = nullptr;
+struct EpochScope {
+  unsigned long long* prev;
+  explicit EpochScope(unsigned long long* e) : prev(t_allocEpoch) { t_allocEpoch = e; }
+  ~EpochScope() { t_allocEpoch = prev; }
+};
+
+// Process teardown.  A host may destroy its handles from static destructors or interpreter finalizers that run after the HIP runtime has
+// begun to shut down, or never destroy them at all (the reference never deletes its extractors, src/Tracking.cc:576-585).  Both ends are
+// covered by one exit handler, armed behind the library's first HIP call so that it runs BEFORE the runtime's own exit handlers:
+//   1. it releases the device side (streams, graphs, events, memory) of every handle that is still alive -- handles leaked into the
+//      runtime's teardown were measured to end the process with SIGSEGV inside __cxa_finalize when a profiler is attached;
+//   2. from then on the destroy / free entry points of this library release host state only and make no device call.
+static std::atomic<bool> g_runtimeDown{false};
+static thread_local bool t_releasingAtExit = false;  // set while the exit handler itself releases the live handles (the runtime is still up)
+struct LiveHandles {
+  std::mutex                             m;
+  std::vector<std::pair<void*, void (*)(void*)>> v;  // object, "release your device side" (must leave the object destroyable on the host side)
+};
+static LiveHandles& live_handles() {
+  static LiveHandles* L = new LiveHandles();  // never destroyed: exit handlers of other libraries may still unregister
+  return *L;
+}
+static void mark_runtime_down() {
+  if (g_runtimeDown.exchange(true)) return;
+  std::vector<std::pair<void*, void (*)(void*)>> v;
+  {
+    std::lock_guard<std::mutex> lock(live_handles().m);
+    v.swap(live_handles().v);
+  }
+  t_releasingAtExit = true;
+  for (auto it = v.rbegin(); it != v.rend(); ++it) it->second(it->first);
+  t_releasingAtExit = false;
+}
+struct DownSentinel {  // the library's own static destruction marks it too (dlclose, or an exit path that skipped atexit handlers)
+  ~DownSentinel() { g_runtimeDown.store(true); }
+} g_downSentinel;
+static void arm_exit_handler() {
+  static std::once_flag armed;
+  std::call_once(armed, [] { atexit(mark_runtime_down); });
+}
 
 template <class T>
 struct DevBuf {
@@ -51,7 +96,7 @@ struct DevBuf {
   size_t n = 0;
   int    ensure(size_t count) {
     if (count <= n) return 0;
-    g_allocEpoch++;  // a recorded hipGraph of orbx_extract holds device addresses: any reallocation retires it (GraphKey::epoch)
+    if (t_allocEpoch) ++*t_allocEpoch; else g_allocEpochFallback++;
     if (p) hipFree(p);
     p = nullptr;
     n = 0;
@@ -64,7 +109,7 @@ struct DevBuf {
     return 0;
   }
   void release() {
-    if (p) hipFree(p);
+    if (p && (!g_runtimeDown.load() || t_releasingAtExit)) hipFree(p);
     p = nullptr;
     n = 0;
   }
@@ -100,19 +145,13 @@ struct orbx_extractor {
   std::vector<int>   quota;
   int                device = 0;
   hipStream_t        stream = nullptr;
-  hipStream_t        stream2 = nullptr;  // side stream: the blur runs beside FAST -> quadtree -> layout
-  hipEvent_t         evFork = nullptr, evJoin = nullptr, evBlur0 = nullptr, evBlur1 = nullptr;
-  // The blur only depends on the pyramid and may run on a side stream beside FAST -> quadtree -> layout
-  // (ORBX_OVERLAP_BLUR=1).  Measured on MI355X it buys nothing -- FAST alone 0.89 ms + blur alone 0.43 ms = 1.30 ms
-  // overlapped: both are VALU-bound and the dispatcher drains one large grid before the other -- so the default keeps
-  // everything on the caller's stream.
   uint8_t*           hOut = nullptr;  // pinned landing buffer of orbx_extract: counts + keypoints + descriptors in one batch of copies
   size_t             hOutCap = 0;
   uint8_t*           hIn = nullptr;   // pinned take-off buffer of orbx_extract: the caller's (pageable) image is copied here first
   size_t             hInCap = 0;
-  bool               overlapBlur = false;
-  bool               latencySideBlur = false;  // ORBX_LATENCY_SIDE_BLUR=1: calls with few frames run the blur on the side stream (measured: the fork and the join cost what the overlap saves)
-  int                overlapMode = 0;  // ORBX_OVERLAP_BLUR: 1 = blur beside FAST, 2 = blur beside the quadtree
+  uint8_t*           hPyr = nullptr;  // pinned host copy of levels >= 1 of orbx_extract's frame (orbx_set_pyramid_download)
+  size_t             hPyrCap = 0;
+  bool               pyrToHost = false, hPyrValid = false;
   bool               profiling = false;
   int                tapMode = 1;  // orbx_set_tap_contraction
   // ---- streaming entry points (orbx_extract_async / orbx_wait): a ring of in-flight chunks.  Chunk k's upload runs on the
@@ -155,9 +194,8 @@ struct orbx_extractor {
   DevBuf<uint8_t> sDl, sDr;
   DevBuf<float>   sU, sDepth;
   DevBuf<int2>    dXtab, dYtab;
-  DevBuf<int4>    dCellDesc;
-  DevBuf<long long> dDbgT;
-  DevBuf<int>     dCellOrder, dCellSlot, dCellCount, dCellOffs, dCandCount, dLvlCount, dCounts;
+    DevBuf<long long> dDbgT;
+  DevBuf<int>     dCellSlot, dCellCount, dCellOffs, dCandCount, dLvlCount, dCounts;
   DevBuf<int4>    dOutIdx;
   DevBuf<uint16_t> dNodeOf, dD, dDIndex, dPushOff, dMultiOff, dKeptRank, dVA, dVB;
   int              octLdsNodeCap = 0, octLdsPtsCap = 0, octLdsBytes = 0;  // dynamic LDS plan of k_octree (makeGeometry)
@@ -167,13 +205,18 @@ struct orbx_extractor {
     int            lap0, lap1, need;
     const uint8_t *    src, *dst;
     int                tapMode, inW, inH;
-    unsigned long long epoch;
+    const uint8_t*     pyrDst;  // pinned pyramid copy (null: not downloaded)
+    unsigned long long epoch, epochFallback;
     bool operator==(const GraphKey& o) const {
       return rows == o.rows && cols == o.cols && step == o.step && lap0 == o.lap0 && lap1 == o.lap1 && need == o.need && src == o.src && dst == o.dst &&
-             tapMode == o.tapMode && inW == o.inW && inH == o.inH && epoch == o.epoch;
+             tapMode == o.tapMode && inW == o.inW && inH == o.inH && pyrDst == o.pyrDst && epoch == o.epoch && epochFallback == o.epochFallback;
     }
   };
+  unsigned long long allocEpoch = 0;  // bumped by (re)allocations of THIS handle's device buffers (EpochScope)
   bool           graphReplay = true, graphSeen = false;  // orbx_extract as a replayed hipGraph (orbx_set_graph_replay)
+  const uint8_t* graphImg0 = nullptr;  // what run() left in bufs.img0 / img0Pitch / img0FrameStride when the graph was recorded: a replay restores it
+  int            graphImg0Pitch = 0;
+  long long      graphImg0Stride = 0;
   GraphKey       graphKey{};
   hipGraphExec_t graphExec = nullptr;
   int              octLatencyFrames = 8;  // up to this many frames per call the quadtree runs a workgroup, not a wave, per (frame, level)
@@ -184,11 +227,20 @@ struct orbx_extractor {
   DevBuf<orbx::PatternTab>   dPattern;
   DevBuf<orbx::KpRec>        dKpOut;
   int                        stagePitch = 0;
-  int                        fastGrid   = 0;
+  // fused pyramid launches (k_pyramid_bands): one plan for batches, one for calls with a handful of frames
+  struct PyrPlanHost {
+    orbx::PyrPlan          plan{};
+    DevBuf<orbx::PyrBand>  dBands;
+    int                    ldsBytes = 0;
+    bool                   valid = false;
+  };
+  bool                       pyrLdsRaised[2] = {false, false};
+  PyrPlanHost                pyrLatency[2];  // calls with a handful of frames: levels [1, mid) and [mid, nlevels) as two launches
+  std::vector<int2>          hYtab;  // host copy of the row tables (band ranges are derived from them)
+  int buildPyrPlan(int firstLevel, int endLevel, int bandRows, int ldsLimit, PyrPlanHost& out);
   DevBuf<orbx::FastTile>     dTiles;      // k_fast_tiles: tile table + XCD-aware launch order
   DevBuf<int>                dTileOrder;
   int                        tileGrid = 0;
-  bool                       fastTwoStage = false;
   orbx::FastLds2             fastLds2{};
 
   // optional cv::resize of the input before extraction (System::TrackMonocular etc., src/System.cc:472-478)
@@ -207,6 +259,67 @@ struct orbx_extractor {
   int run(const uint8_t* d_imgs, int B, int rows, int cols, size_t step, size_t frameStride, int lap0, int lap1, orbx::KpRec* d_kps,
           uint8_t* d_desc, int* d_counts, int cap, hipStream_t s);
 };
+
+// Row ranges of k_pyramid_bands for levels [firstLevel, endLevel) with bands of `bandRows` rows of level endLevel - 1; out.valid = false
+// when the LDS budget does not allow it.
+int orbx_extractor::buildPyrPlan(int firstLevel, int endLevel, int bandRows, int ldsLimit, PyrPlanHost& out) {
+  using namespace orbx;
+  out.valid = false;
+  const FrameGeom& g = geom;
+  const int        last = endLevel - 1;
+  if (firstLevel < 1 || firstLevel > last || endLevel > g.nlevels || bandRows < 1) return 0;
+  const int            nb = (g.lv[last].h + bandRows - 1) / bandRows;
+  std::vector<PyrBand> bands(nb);
+  std::vector<int>     cLo(nb), cHi(nb), nLo(nb), nHi(nb);  // computed rows of the level above / needed rows of this one (inclusive)
+  std::vector<int>     yRows(nb, 0);
+  for (int k = 0; k < nb; k++) {
+    cLo[k] = k * bandRows, cHi[k] = std::min((k + 1) * bandRows, g.lv[last].h) - 1;
+    PyrBand& B = bands[k];
+    memset(&B, 0, sizeof(B));
+    B.lo[last] = B.ownLo[last] = (short)cLo[k], B.n[last] = B.ownN[last] = (short)(cHi[k] - cLo[k] + 1);
+    yRows[k] = B.n[last];
+  }
+  int half = 0;
+  for (int l = last - 1; l >= firstLevel - 1; l--) {
+    const LevelGeom& L  = g.lv[l];
+    const int2*      yt = hYtab.data() + g.lv[l + 1].ytabOff;
+    for (int k = 0; k < nb; k++) {
+      nLo[k] = std::min(std::max(yt[cLo[k]].x, 0), L.h - 1);
+      nHi[k] = std::min(std::max(yt[cHi[k]].x + 1, 0), L.h - 1);
+    }
+    for (int k = 0; k < nb; k++) {
+      PyrBand& B = bands[k];
+      int      lo = nLo[k], hi = nHi[k];
+      if (l >= firstLevel) {  // rows of this level nobody above needs still have to be produced: the bands partition [0, h)
+        const int oLo = k == 0 ? 0 : nLo[k], oHi = k == nb - 1 ? L.h - 1 : nLo[k + 1] - 1;
+        B.ownLo[l] = (short)oLo, B.ownN[l] = (short)std::max(oHi - oLo + 1, 0);
+        if (oHi >= oLo) lo = std::min(lo, oLo), hi = std::max(hi, oHi);
+        yRows[k] += hi - lo + 1;
+      }
+      B.lo[l] = (short)lo, B.n[l] = (short)(hi - lo + 1);
+      cLo[k] = lo, cHi[k] = hi;
+      half   = std::max(half, (hi - lo + 2) * ((L.w + 3) & ~3));  // one spare row: the row below the last one is addressed with weight 0
+    }
+  }
+  half = alignUp(half + 16, 16);
+  auto magic = [](unsigned d) { return d <= 1 ? 0u : 0xffffffffu / d + 1u; };
+  PyrPlan& P = out.plan;
+  memset(&P, 0, sizeof(P));
+  P.firstLevel = firstLevel, P.endLevel = endLevel, P.nbands = nb, P.ldsHalf = half;
+  int xtEntries = 0;
+  for (int l = 0; l < g.nlevels; l++) {
+    P.quadMagic[l] = magic((unsigned)((g.lv[l].w + 3) >> 2));
+    if (l >= firstLevel && l < endLevel) P.xtOff[l] = xtEntries, xtEntries += ((g.lv[l].w + 3) >> 2) * 4;
+  }
+  P.xtLds = 2 * half;
+  P.ytLds = P.xtLds + xtEntries * 8;
+  out.ldsBytes = P.ytLds + *std::max_element(yRows.begin(), yRows.end()) * 8;
+  if (out.ldsBytes > ldsLimit) return 0;
+  if (out.dBands.ensure(bands.size())) return -3;
+  HIP_TRY(hipMemcpy(out.dBands.p, bands.data(), bands.size() * sizeof(PyrBand), hipMemcpyHostToDevice));
+  out.valid = true;
+  return 0;
+}
 
 // Level sizes, FAST grids, quadtree roots, buffer offsets and resize tables for one image size.
 int orbx_extractor::makeGeometry(int rows, int cols) {
@@ -317,68 +430,10 @@ int orbx_extractor::makeGeometry(int rows, int cols) {
   g.totalBlurTiles = tileBase;
   g.pyrBytes       = alignUp(pyrOff, 256);
   g.blurBytes      = alignUp(blurOff, 256);
-  // FAST launch order: cell rows dealt round-robin to the 8 XCDs (block b runs on XCD b % 8)
-  std::vector<int> cellOrder;
-  {
-    // longest-row-first onto the least loaded XCD: equal cell counts per XCD (rows differ from 17 to 4 cells at VGA)
-    struct Row {
-      int level, i, cells;
-    };
-    std::vector<Row> rows;
-    for (int l = 0; l < nlevels; l++)
-      for (int i = 0; i < g.lv[l].nRows; i++) rows.push_back({l, i, g.lv[l].nCols});
-    std::stable_sort(rows.begin(), rows.end(), [](const Row& a, const Row& b) { return a.cells > b.cells; });
-    std::vector<std::vector<int>> perXcd(8);
-    for (const Row& r : rows) {
-      int best = 0;
-      for (int x = 1; x < 8; x++)
-        if (perXcd[x].size() < perXcd[best].size()) best = x;
-      for (int j = 0; j < r.cells; j++) perXcd[best].push_back(g.lv[r.level].cellBase + r.i * g.lv[r.level].nCols + j);
-    }
-    size_t per = 0;
-    for (auto& v : perXcd) per = std::max(per, v.size());
-    cellOrder.assign(per * 8, -1);
-    for (int x = 0; x < 8; x++)
-      for (size_t k = 0; k < perXcd[x].size(); k++) cellOrder[k * 8 + x] = perXcd[x][k];
-    fastGrid = (int)cellOrder.size();
-  }
-  if (dCellOrder.ensure(cellOrder.size() + 1)) return -3;
-  HIP_TRY(hipMemcpy(dCellOrder.p, cellOrder.data(), cellOrder.size() * sizeof(int), hipMemcpyHostToDevice));
-  // pre-decoded geometry per order slot (FastCellDesc in orbx_kernels.h)
-  {
-    std::vector<int4> desc(3 * cellOrder.size());
-    for (size_t sidx = 0; sidx < cellOrder.size(); sidx++) {
-      int4 d0 = make_int4(-1, 0, 0, 0), d1 = make_int4(0, 0, 0, 0), d2 = make_int4(0, 0, 0, 0);
-      const int cell = cellOrder[sidx];
-      if (cell >= 0) {
-        int l = 0;
-        while (l + 1 < nlevels && cell >= g.lv[l + 1].cellBase) l++;
-        const LevelGeom& L = g.lv[l];
-        const int ci = cell - L.cellBase, ci_i = ci / L.nCols, ci_j = ci - ci_i * L.nCols;
-        const int iniY = kMinBorder + ci_i * L.hCell, iniX = kMinBorder + ci_j * L.wCell;
-        int       tw = 0, th = 0, valid = 0;
-        if (!(iniY >= L.maxBY - 3 || iniX >= L.maxBX - 6)) {
-          tw = std::min(iniX + L.wCell + 6, L.maxBX) - iniX;
-          th = std::min(iniY + L.hCell + 6, L.maxBY) - iniY;
-          valid = (tw - 6 > 0 && th - 6 > 0) ? 1 : 0;
-        }
-        d0 = make_int4(cell, l, iniX | (iniY << 16), tw | (th << 8) | (valid << 16));
-        d1 = make_int4((ci_j * L.wCell) | ((ci_i * L.hCell) << 16), L.slotBase + cellSlot[cell], L.pyrOff + iniY * L.pitch + iniX, L.pitch);
-        if (valid) {  // dividers of the kernel's idx -> (row, column) maps (div_magic): tile dwords per row, interior width
-          auto magic = [](unsigned d) { return d == 1 ? 0u : 0xffffffffu / d + 1u; };
-          const unsigned tw4a = (unsigned)(((iniX & 3) + tw + 3) >> 2), tw4b = (unsigned)((tw + 3) >> 2);
-          d2 = make_int4((int)(0xffffffffu / tw4a + 1u), (int)(0xffffffffu / tw4b + 1u), (int)magic((unsigned)(tw - 6)), 0);
-        }
-      }
-      desc[3 * sidx] = d0, desc[3 * sidx + 1] = d1, desc[3 * sidx + 2] = d2;
-    }
-    if (dCellDesc.ensure(desc.size() + 2)) return -3;
-    HIP_TRY(hipMemcpy(dCellDesc.p, desc.data(), desc.size() * sizeof(int4), hipMemcpyHostToDevice));
-  }
   // ---- k_fast_tiles: tiles = runs of horizontally adjacent valid cells of one cell row (orbx_fast_tiles.h)
   {
     auto magic = [](unsigned d) { return d <= 1 ? 0u : 0xffffffffu / d + 1u; };
-    const int              kTileBudget = getenv("ORBX_FAST_TILE_BYTES") ? atoi(getenv("ORBX_FAST_TILE_BYTES")) : 8192;  // LDS bytes of one pixel tile
+    const int              kTileBudget = 8192;  // LDS bytes of one pixel tile
     std::vector<FastTile>  tiles;
     struct RowRef {
       int first, count, px;
@@ -482,16 +537,12 @@ int orbx_extractor::makeGeometry(int rows, int cols) {
     fl.scoreOff = alignUp(16 + region, 16);
     fl.scoreBytes = region;
     fl.candOff  = fl.scoreOff + region;
-    fl.candCap  = getenv("ORBX_FAST_CAND_CAP") ? atoi(getenv("ORBX_FAST_CAND_CAP")) : 2048;
+    // candidate list entries; lanes whose survivors do not fit score them themselves (ORBX_FAST_CAND_CAP: tests shrink the list to reach that path)
+    fl.candCap  = getenv("ORBX_FAST_CAND_CAP") ? std::max(atoi(getenv("ORBX_FAST_CAND_CAP")), 2) : 2048;
     fl.mask1Off = alignUp(fl.candOff + 2 * fl.candCap, 16);
     fl.mask2Off = fl.mask1Off + 4 * maxCells * maxW;
     fl.cntOff   = fl.mask2Off + 4 * maxCells * maxW;
-    fl.stageOff = alignUp(fl.cntOff + 4 * (maxCells + 3), 16);
-    fastTwoStage = getenv("ORBX_FAST_TWO_STAGE") != nullptr;
-    // the staging slices and the corner list only exist in the two-stage form: 2 KB more LDS per workgroup costs a resident workgroup
-    fl.listCOff = fl.stageOff + (fastTwoStage ? 4 * 128 * 2 : 0);
-    fl.listCCap = fastTwoStage ? 512 : 0;
-    fl.total    = alignUp(fl.listCOff + 2 * fl.listCCap, 16);
+    fl.total    = alignUp(fl.cntOff + 4 * (maxCells + 3), 16);
     if (fl.total > 160 * 1024) {
       g_err = "FAST tile LDS plan exceeds 160 KB";
       return -2;
@@ -510,12 +561,7 @@ int orbx_extractor::makeGeometry(int rows, int cols) {
     int maxCap = 0;
     for (int l = 0; l < nlevels; l++) maxCap = std::max(maxCap, g.lv[l].nodeCap);
     const int fixed = kOctFixedInts * 4, nodeBytes = maxCap * kOctNodeBytes;
-    static const int ldsMode = getenv("ORBX_OCT_LDS") ? atoi(getenv("ORBX_OCT_LDS")) : 2;  // A/B: 0 = state in global memory, 1 = node arrays only, 2 = nodes + point labels
-    if (ldsMode == 0) {
-      octLdsNodeCap = 0, octLdsBytes = fixed, octLdsPtsCap = 0;
-    } else if (ldsMode == 1 && fixed + nodeBytes <= 65536) {
-      octLdsNodeCap = maxCap, octLdsBytes = fixed + nodeBytes, octLdsPtsCap = 0;
-    } else if (fixed + nodeBytes + 2 * 512 <= 20224) {
+    if (fixed + nodeBytes + 2 * 512 <= 20224) {
       octLdsNodeCap = maxCap, octLdsBytes = 20224, octLdsPtsCap = (octLdsBytes - fixed - nodeBytes) / 2;
     } else if (fixed + nodeBytes + 2 * 4096 <= 40960) {
       // larger quotas (2000 features: 30 KB of node state): 4 problems per CU, and 4096 point labels still ride along
@@ -529,6 +575,19 @@ int orbx_extractor::makeGeometry(int rows, int cols) {
   geom     = g;
   haveGeom = true;
   capB     = 0;  // workspace must be re-laid out
+  // fused pyramid launches of the latency form: the chain in two halves (shorter chains recompute fewer shared rows)
+  hYtab = yt;
+  pyrLatency[0].valid = pyrLatency[1].valid = false;
+  if (g.nlevels > 1) {
+    const int mid = std::min((g.nlevels + 1) / 2, g.nlevels - 1);
+    const int ends[3] = {1, g.nlevels > 2 ? mid : g.nlevels, g.nlevels};
+    int       rc2 = 0;
+    for (int part = 0; part < 2; part++) {
+      if (ends[part] >= ends[part + 1]) continue;
+      for (int rowsPerBand : {8, 4, 2, 1})
+        if (!pyrLatency[part].valid && (rc2 = buildPyrPlan(ends[part], ends[part + 1], rowsPerBand, 150 * 1024, pyrLatency[part]))) return rc2;
+    }
+  }
   return 0;
 }
 
@@ -547,7 +606,7 @@ int orbx_extractor::ensureWorkspace(int rows, int cols, int B) {
       dLvlCount.ensure(nb * g.nlevels) || dOutIdx.ensure(2 * nb * g.totalKp))
     return -3;
   orbx::Bufs& b = bufs;
-  b.pyr = dPyr.p, b.blur = dBlur.p, b.xtab = dXtab.p, b.ytab = dYtab.p, b.cellSlot = dCellSlot.p, b.cellOrder = dCellOrder.p, b.cellDesc = dCellDesc.p, b.slots = dSlots.p;
+  b.pyr = dPyr.p, b.blur = dBlur.p, b.xtab = dXtab.p, b.ytab = dYtab.p, b.cellSlot = dCellSlot.p, b.slots = dSlots.p;
   b.cellCount = dCellCount.p, b.cand = dCand.p, b.nodeOf = dNodeOf.p, b.cellOffs = dCellOffs.p;
   b.nodesA = dNodesA.p, b.nodesB = dNodesB.p, b.childCnt = dChildCnt.p, b.childIdx = dChildIdx.p, b.D = dD.p;
   b.dIndex = dDIndex.p, b.nCh = dNCh.p, b.pushOff = dPushOff.p, b.multiOff = dMultiOff.p, b.keptRank = dKeptRank.p, b.vA = dVA.p;
@@ -607,18 +666,20 @@ int orbx_extractor::run(const uint8_t* d_imgs, int B, int rows, int cols, size_t
   if (rc) return rc;
   const FrameGeom& g = geom;
   Bufs             b = bufs;
-  if (getenv("ORBX_DBG_OCT")) {
+  b.dbgT = nullptr;
+#ifdef ORBX_TUNING
+  if (getenv("ORBX_DBG_OCT")) {  // quadtree phase stamps (orbx_debug_octree_times)
     if (dDbgT.ensure((size_t)B * g.nlevels * 8)) return -3;
     HIP_TRY(hipMemsetAsync(dDbgT.p, 0, (size_t)B * g.nlevels * 8 * sizeof(long long), s));
     b.dbgT = dDbgT.p;
-  } else {
-    b.dbgT = nullptr;
   }
+#endif
   b.img0            = d_imgs;
   b.img0FrameStride = (long long)frameStride;
   b.img0Pitch       = (int)step;
   bufs              = b;  // remembered for the pyramid / debug accessors
   lastB             = B;
+  hPyrValid         = false;  // the device pyramid is about to change; orbx_extract re-validates its host copy
   const bool prof   = profiling;
   if (prof && !evValid) {
     for (auto& slot : ev)
@@ -634,10 +695,8 @@ int orbx_extractor::run(const uint8_t* d_imgs, int B, int rows, int cols, size_t
     const FrameGeom& gg = geom;
     int              edgeBlocks = 0;
     for (int l = al4 ? 0 : 1; l < gg.nlevels; l++) edgeBlocks += blur_edge_blocks(gg.lv[l]);
-    static const bool split = getenv("ORBX_BLUR_SPLIT") != nullptr;  // A/B: interior and edge items as two launches
-    if (split || edgeBlocks == 0) {
+    if (edgeBlocks == 0) {
       hipLaunchKernelGGL(k_blur_levels, dim3(8 * ((gg.totalBlurTiles + 7) / 8), B), dim3(256), 0, st, bufs, gg, l0a);
-      if (edgeBlocks > 0) hipLaunchKernelGGL(k_blur_edges, dim3(edgeBlocks, B), dim3(256), 0, st, bufs, gg, al4 ? 0 : 1);
     } else {
       const int edgePad = 8 * ((edgeBlocks + 7) / 8);
       hipLaunchKernelGGL(k_blur_all, dim3(edgePad + 8 * ((gg.totalBlurTiles + 7) / 8), B), dim3(256), 0, st, bufs, gg, l0a, al4 ? 0 : 1, edgeBlocks, edgePad);
@@ -648,79 +707,50 @@ int orbx_extractor::run(const uint8_t* d_imgs, int B, int rows, int cols, size_t
     }
   };
   if (prof) HIP_TRY(hipEventRecord(ev[0], s));
-  for (int l = 1; l < g.nlevels; l++) {
-    const int tx = (g.lv[l].w + kRsTileW - 1) / kRsTileW, ty = (g.lv[l].h + kRsTileH - 1) / kRsTileH;
-    hipLaunchKernelGGL(k_resize_level, dim3(8 * tx, ty, (B + 7) / 8), dim3(256), 0, s, b, g, l, B);
-  }
-  auto forkBlur = [&]() -> int {  // the blur only needs the pyramid: side stream (a hardware queue of its own), joined before orientation
-    HIP_TRY(hipEventRecord(evFork, s));
-    HIP_TRY(hipStreamWaitEvent(stream2, evFork, 0));
-    launchBlur(stream2);
-    HIP_TRY(hipEventRecord(evJoin, stream2));
-    return 0;
-  };
-  // Latency form (a handful of frames per call): nothing is resource-bound, the call is a chain of dependent launches -- the blur, which
-  // only needs the pyramid, can run on the side stream beside FAST -> quadtree -> layout and be joined before orientation.  Off by
-  // default: on MI355X the cross-stream fork and join cost ~10 us each, the 19 us blur they hide (0.201 -> 0.187 ms eager, but
-  // 0.176 -> 0.189 ms for the replayed graph).
-  const bool sideBlur = overlapBlur || (B <= octLatencyFrames && latencySideBlur);
-  if (sideBlur && !stream2) {
-    const uint32_t allCus[8] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
-    if (hipExtStreamCreateWithCUMask(&stream2, 8, allCus) != hipSuccess || hipEventCreateWithFlags(&evFork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&evJoin, hipEventDisableTiming) != hipSuccess) {
-      g_err = "hipStreamCreate/hipEventCreate (side stream) failed";
-      return -3;
-    }
-  }
-  if (sideBlur && (!overlapBlur || overlapMode == 1) && (rc = forkBlur())) return rc;  // (throughput form, beside FAST: both VALU-bound, measured, no gain)
-  if (prof) HIP_TRY(hipEventRecord(ev[1], s));
-  static const bool useCells = getenv("ORBX_FAST_CELLS") != nullptr;  // first-generation kernel (one workgroup per cell), kept for A/B runs
-  if (!useCells) {
-    const int t1 = std::min(std::max(iniTh, 0), 255), t2 = std::min(std::max(minTh, 0), 255);
-    static const int dbg = getenv("ORBX_DBG_SKIP_FAST") ? atoi(getenv("ORBX_DBG_SKIP_FAST")) : 0;  // ablation switch (tuning only)
-    // Default: all four opposite pairs in the dense pass.  ORBX_FAST_TWO_STAGE=1 selects the two-stage pre-test (N-S / E-W pairs densely,
-    // the diagonals on the compacted survivors, wave-local batching for the score): 33 % fewer dense instructions, but measured SLOWER
-    // (0.395 -> 0.429 ms per 256 VGA frames): the extra dependent LDS round trips of stage 2 cost more than the instructions saved.
-    const bool oneStage = !fastTwoStage;
-#define ORBX_LAUNCH_TILES(AL, TS) hipLaunchKernelGGL((k_fast_tiles<AL, TS>), dim3(tileGrid, B), dim3(kFastTileThreads), fastLds2.total, s, b, g, dTiles.p, dTileOrder.p, t1, t2, fastLds2, dbg)
-    if (al4) {
-      if (oneStage) ORBX_LAUNCH_TILES(true, false); else ORBX_LAUNCH_TILES(true, true);
-    } else {
-      if (oneStage) ORBX_LAUNCH_TILES(false, false); else ORBX_LAUNCH_TILES(false, true);
-    }
-#undef ORBX_LAUNCH_TILES
-  } else
   {
-    const int  per  = fastGrid / 8;  // order-table slots per XCD
-    const dim3 grid(8 * ((per + kFastCellsPerBlock - 1) / kFastCellsPerBlock), B);
-    const int  t1 = std::min(std::max(iniTh, 0), 255), t2 = std::min(std::max(minTh, 0), 255);
-    const int dbg = getenv("ORBX_DBG_SKIP_FAST") ? atoi(getenv("ORBX_DBG_SKIP_FAST")) : 0;  // ablation switch (tuning)
-    // tile geometry of this image size: tiles are staged from the aligned column below iniX (up to +3 columns)
-    int maxW = 0, maxH = 0;
-    for (int l = 0; l < g.nlevels; l++) maxW = std::max(maxW, g.lv[l].wCell), maxH = std::max(maxH, g.lv[l].hCell);
-    const bool    small = maxW + 9 <= 52 && maxH + 6 <= kFastSmallPre * (kFastThreads / 16);  // staging map of the 52-byte stride: 16 lanes x 8 rows per step
-    const int     tsSel = small ? 52 : kFastTileMax;
-    orbx::FastLds fl;
-    fl.tileBytes = alignUp(tsSel * (maxH + 6), 16);
-    fl.maxInt    = alignUp(maxW * maxH, 2);
-    fl.kpCap     = ((maxW + 1) / 2) * ((maxH + 1) / 2) + 64;
-    const size_t ldsBytes = 2 * (size_t)fl.tileBytes + 2 * (size_t)(fl.maxInt + fl.kpCap);
-#define ORBX_LAUNCH_FAST(AL, NP, TS) hipLaunchKernelGGL((k_fast_cells<AL, NP, TS>), grid, dim3(kFastThreads), ldsBytes, s, b, g, t1, t2, fastGrid, dbg, fl)
-    if (al4) {
-      if (small)
-        ORBX_LAUNCH_FAST(true, kFastSmallPre, 52);
+    // batches: one launch per level.  A handful of frames: the chain in two launches of k_pyramid_bands (levels they do not cover -- a
+    // plan that did not fit the LDS -- fall back to their own launches).
+    int covered[2][2] = {{0, 0}, {0, 0}};
+    if (B <= octLatencyFrames)
+      for (int part = 0; part < 2; part++)
+        if (pyrLatency[part].valid) covered[part][0] = pyrLatency[part].plan.firstLevel, covered[part][1] = pyrLatency[part].plan.endLevel;
+    for (int l = 1; l < g.nlevels;) {
+      int part = -1;
+      for (int q = 0; q < 2; q++)
+        if (covered[q][0] == l && covered[q][1] > l) part = q;
+      if (part < 0) {
+        const int tx = (g.lv[l].w + kRsTileW - 1) / kRsTileW, ty = (g.lv[l].h + kRsTileH - 1) / kRsTileH;
+        hipLaunchKernelGGL(k_resize_level, dim3(8 * tx, ty, (B + 7) / 8), dim3(256), 0, s, b, g, l, B);
+        l++;
+        continue;
+      }
+      const PyrPlanHost& pp = pyrLatency[part];
+      bool* const        raised = pyrLdsRaised;  // more than 64 KB of dynamic LDS has to be asked for, once per kernel (and device: per handle)
+      const void*        fn = al4 ? (const void*)k_pyramid_bands<true> : (const void*)k_pyramid_bands<false>;
+      if (pp.ldsBytes > 64 * 1024 && !raised[al4 ? 1 : 0]) {
+        HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        raised[al4 ? 1 : 0] = true;
+      }
+      if (al4)
+        hipLaunchKernelGGL(k_pyramid_bands<true>, dim3(pp.plan.nbands, B), dim3(kPyrBandThreads), pp.ldsBytes, s, b, g, pp.dBands.p, pp.plan, B);
       else
-        ORBX_LAUNCH_FAST(true, kFastPrefetchMax, kFastTileMax);
-    } else {
-      if (small)
-        ORBX_LAUNCH_FAST(false, kFastSmallPre, 52);
-      else
-        ORBX_LAUNCH_FAST(false, kFastPrefetchMax, kFastTileMax);
+        hipLaunchKernelGGL(k_pyramid_bands<false>, dim3(pp.plan.nbands, B), dim3(kPyrBandThreads), pp.ldsBytes, s, b, g, pp.dBands.p, pp.plan, B);
+      l = pp.plan.endLevel;
     }
-#undef ORBX_LAUNCH_FAST
   }
-  // mode 2: beside the quadtree -- a latency-bound launch of 8 one-wave problems per CU that leaves the vector units idle
-  if (overlapBlur && overlapMode == 2 && (rc = forkBlur())) return rc;
+  if (prof) HIP_TRY(hipEventRecord(ev[1], s));
+  {
+    const int t1 = std::min(std::max(iniTh, 0), 255), t2 = std::min(std::max(minTh, 0), 255);
+    int       dbg = 0;
+#ifdef ORBX_TUNING
+    static const int dbgEnv = getenv("ORBX_DBG_SKIP_FAST") ? atoi(getenv("ORBX_DBG_SKIP_FAST")) : 0;  // phase ablation (wrong results by design)
+    dbg = dbgEnv;
+#endif
+    if (al4)
+      hipLaunchKernelGGL((k_fast_tiles<true>), dim3(tileGrid, B), dim3(kFastTileThreads), fastLds2.total, s, b, g, dTiles.p, dTileOrder.p, t1, t2, fastLds2, dbg);
+    else
+      hipLaunchKernelGGL((k_fast_tiles<false>), dim3(tileGrid, B), dim3(kFastTileThreads), fastLds2.total, s, b, g, dTiles.p, dTileOrder.p, t1, t2, fastLds2, dbg);
+  }
   if (prof) HIP_TRY(hipEventRecord(ev[2], s));
   // level-major grid: the large levels start first and every level spreads over all XCDs
   if (B <= octLatencyFrames)
@@ -730,10 +760,7 @@ int orbx_extractor::run(const uint8_t* d_imgs, int B, int rows, int cols, size_t
   if (prof) HIP_TRY(hipEventRecord(ev[3], s));
   hipLaunchKernelGGL(k_layout, dim3(B), dim3(256), 0, s, b, g, lap0, lap1, d_counts, cap);
   if (prof) HIP_TRY(hipEventRecord(ev[4], s));
-  if (sideBlur)
-    HIP_TRY(hipStreamWaitEvent(s, evJoin, 0));  // join
-  else
-    launchBlur(s);
+  launchBlur(s);
   if (prof) HIP_TRY(hipEventRecord(ev[5], s));
   {
     const int nbPerFrame = (g.totalKp + kOdKpPerBlock - 1) / kOdKpPerBlock;
@@ -757,7 +784,10 @@ const char* orbx_last_error(void) { return g_err.c_str(); }
 // Not part of include/orbx.h: the matcher and vocabulary translation units report through the same per-thread slot.
 void orbx_internal_set_error(const char* s) { g_err = s ? s : ""; }
 
-void* orbx_stream_create(int device_id);
+static hipStream_t create_queue_stream(int device_id);
+void  orbx_internal_register(void* obj, void (*release_device)(void*));
+void  orbx_internal_unregister(void* obj);
+static void release_device_side(orbx_extractor* h);
 
 int orbx_create(orbx_t** out, int nfeatures, float scale_factor, int nlevels, int ini_th_fast, int min_th_fast, int device_id) {
   if (!out) return -2;
@@ -768,13 +798,11 @@ int orbx_create(orbx_t** out, int nfeatures, float scale_factor, int nlevels, in
   }
   HIP_TRY(hipSetDevice(device_id));
   orbx_extractor* h = new orbx_extractor();
+  EpochScope      es(&h->allocEpoch);
+  arm_exit_handler();  // after the first HIP call above: runs before the runtime's own exit handlers
   h->nfeatures = nfeatures, h->nlevels = nlevels, h->iniTh = ini_th_fast, h->minTh = min_th_fast, h->scaleFactor = scale_factor;
   h->device = device_id;
-  h->overlapMode = getenv("ORBX_OVERLAP_BLUR") ? atoi(getenv("ORBX_OVERLAP_BLUR")) : 0;
   h->graphReplay = !(getenv("ORBX_GRAPH") != nullptr && atoi(getenv("ORBX_GRAPH")) == 0);  // on by default; ORBX_GRAPH=0 or orbx_set_graph_replay(h, 0) turns it off
-  if (getenv("ORBX_OCT_LATENCY_FRAMES")) h->octLatencyFrames = atoi(getenv("ORBX_OCT_LATENCY_FRAMES"));  // tuning: 0 = always one wave per problem
-  h->overlapBlur = h->overlapMode != 0;
-  if (getenv("ORBX_LATENCY_SIDE_BLUR")) h->latencySideBlur = atoi(getenv("ORBX_LATENCY_SIDE_BLUR")) != 0;
   // src/ORBextractor.cc:409-440, exact float sequence
   h->sf.resize(nlevels), h->sigma2.resize(nlevels), h->invSf.resize(nlevels), h->invSigma2.resize(nlevels), h->quota.resize(nlevels);
   h->sf[0] = 1.0f, h->sigma2[0] = 1.0f;
@@ -796,20 +824,10 @@ int orbx_create(orbx_t** out, int nfeatures, float scale_factor, int nlevels, in
   }
   h->quota[nlevels - 1] = std::max(nfeatures - sumFeatures, 0);
   // the handle's own stream owns a hardware queue (see orbx_stream_create): two handles driven side by side then really overlap
-  h->stream    = (hipStream_t)orbx_stream_create(device_id);
+  h->stream    = create_queue_stream(device_id);
   hipError_t e = h->stream ? hipSuccess : hipErrorUnknown;
   if (e != hipSuccess) {
     g_err = std::string("hipStreamCreate: ") + hipGetErrorString(e);
-    delete h;
-    return -3;
-  }
-  // The side stream exists only when asked for: HIP streams share a handful of hardware queues, and every idle stream of a handle
-  // makes it likelier that two streams which should overlap (kernels / copy-out) land on the same queue.
-  const uint32_t allCus[8] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
-  if (h->overlapBlur && (hipExtStreamCreateWithCUMask(&h->stream2, 8, allCus) != hipSuccess ||  // CU-masked stream = own hardware queue
-                         hipEventCreateWithFlags(&h->evFork, hipEventDisableTiming) != hipSuccess ||
-                         hipEventCreateWithFlags(&h->evJoin, hipEventDisableTiming) != hipSuccess)) {
-    g_err = "hipStreamCreate/hipEventCreate (side stream) failed";
     delete h;
     return -3;
   }
@@ -837,17 +855,14 @@ int orbx_create(orbx_t** out, int nfeatures, float scale_factor, int nlevels, in
     delete h;
     return -3;
   }
+  orbx_internal_register(h, [](void* p) { release_device_side(static_cast<orbx_extractor*>(p)); });
   *out = h;
   return 0;
 }
 
-void orbx_destroy(orbx_t* h) {
-  if (!h) return;
+// Everything of a handle that lives on the device or in the runtime; leaves the host object valid (all pointers nulled).
+static void release_device_side(orbx_extractor* h) {
   hipSetDevice(h->device);
-  if (h->stream2) {
-    hipStreamSynchronize(h->stream2);
-    hipStreamDestroy(h->stream2);
-  }
   if (h->stream) {
     hipStreamSynchronize(h->stream);
     hipStreamDestroy(h->stream);
@@ -855,6 +870,7 @@ void orbx_destroy(orbx_t* h) {
   if (h->graphExec) hipGraphExecDestroy(h->graphExec);
   if (h->hOut) hipHostFree(h->hOut);
   if (h->hIn) hipHostFree(h->hIn);
+  if (h->hPyr) hipHostFree(h->hPyr);
   for (hipStream_t st : {h->sIn, h->sOut})
     if (st) {
       hipStreamSynchronize(st);
@@ -867,17 +883,24 @@ void orbx_destroy(orbx_t* h) {
     if (sl.hIn) hipHostFree(sl.hIn);
     if (sl.hOut) hipHostFree(sl.hOut);
   }
-  for (hipEvent_t e : {h->evFork, h->evJoin, h->evBlur0, h->evBlur1})
-    if (e) hipEventDestroy(e);
   if (h->evValid)
     for (auto& slot : h->ev)
       for (auto& e : slot) hipEventDestroy(e);
   h->dPyr.release(), h->dBlur.release(), h->dStereoSad.release(), h->dStereoRowStart.release(), h->dStereoRowIdx.release(), h->sSad.release(), h->sKept.release(), h->sRow.release(), h->sRidx.release(), h->sKl.release(), h->sKr.release(), h->sDl.release(), h->sDr.release(), h->sU.release(), h->sDepth.release(), h->dRaw.release(), h->dPre.release(), h->dPreX.release(), h->dPreY.release(), h->dStage.release(), h->dDescOut.release(), h->dOutBlock.release(), h->dXtab.release(), h->dYtab.release();
-  h->dTiles.release(), h->dTileOrder.release(), h->dCellDesc.release(), h->dCellOrder.release(), h->dCellSlot.release(), h->dCellCount.release(), h->dNodeOf.release(), h->dCellOffs.release();
+  h->pyrLatency[0].dBands.release(), h->pyrLatency[1].dBands.release(), h->dTiles.release(), h->dTileOrder.release(), h->dCellSlot.release(), h->dCellCount.release(), h->dNodeOf.release(), h->dCellOffs.release();
   h->dD.release(), h->dDIndex.release(), h->dNCh.release(), h->dPushOff.release(), h->dMultiOff.release();
   h->dKeptRank.release(), h->dVA.release(), h->dVB.release(), h->dCandCount.release(), h->dLvlCount.release(), h->dOutIdx.release();
   h->dCounts.release(), h->dSlots.release(), h->dCand.release(), h->dLvlKp.release(), h->dNodesA.release(), h->dNodesB.release();
   h->dChildCnt.release(), h->dChildIdx.release(), h->dPattern.release(), h->dKpOut.release();
+  h->stream = nullptr, h->graphExec = nullptr, h->hOut = h->hIn = h->hPyr = nullptr, h->hOutCap = h->hInCap = h->hPyrCap = 0, h->sIn = h->sOut = nullptr;
+  for (auto& sl : h->slots) sl.evIn = sl.evCompute = sl.evDone = nullptr, sl.hIn = sl.hOut = nullptr, sl.hInCap = sl.hOutCap = 0;
+  h->evValid = false, h->haveGeom = false, h->capB = 0;
+}
+
+void orbx_destroy(orbx_t* h) {
+  if (!h) return;
+  orbx_internal_unregister(h);
+  if (!g_runtimeDown.load()) release_device_side(h);  // else: process teardown, the exit handler has already released it (or the runtime is gone)
   delete h;
 }
 
@@ -906,7 +929,7 @@ int orbx_set_input_resize(orbx_t* h, int new_cols, int new_rows) {
 // first), and two streams that share one execute in submission order -- chunks that are meant to overlap (the latency-bound quadtree and
 // claim resolution of one chunk beside the VALU-bound FAST / blur / top-k of another) then do not.  A stream created with a CU mask
 // always gets a queue of its own; the mask enables every CU.
-void* orbx_stream_create(int device_id) {
+static hipStream_t create_queue_stream(int device_id) {
   if (hipSetDevice(device_id) != hipSuccess) return nullptr;
   const uint32_t allCus[8] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
   hipStream_t    st = nullptr;
@@ -917,11 +940,23 @@ void* orbx_stream_create(int device_id) {
       return nullptr;
     }
   }
+  return st;
+}
+
+void* orbx_stream_create(int device_id) {
+  hipStream_t st = create_queue_stream(device_id);
+  if (st)
+    orbx_internal_register((void*)st, [](void* p) {
+      hipStreamSynchronize((hipStream_t)p);
+      hipStreamDestroy((hipStream_t)p);
+    });
   return (void*)st;
 }
 
 void orbx_stream_destroy(void* stream) {
-  if (stream) {
+  if (!stream) return;
+  orbx_internal_unregister(stream);
+  if (!g_runtimeDown.load()) {
     hipStreamSynchronize((hipStream_t)stream);
     hipStreamDestroy((hipStream_t)stream);
   }
@@ -930,6 +965,13 @@ void orbx_stream_destroy(void* stream) {
 int orbx_set_tap_contraction(orbx_t* h, int mode) {
   if (!h || mode < 0 || mode > 2) return -2;
   h->tapMode = mode;
+  return 0;
+}
+
+int orbx_set_pyramid_download(orbx_t* h, int enable) {
+  if (!h) return -2;
+  h->pyrToHost = enable != 0;
+  if (!h->pyrToHost) h->hPyrValid = false;
   return 0;
 }
 
@@ -943,6 +985,7 @@ int orbx_set_graph_replay(orbx_t* h, int enable) {
 
 int orbx_max_keypoints(orbx_t* h, int rows, int cols) {
   if (!h) return -2;
+  EpochScope es(&h->allocEpoch);
   hipSetDevice(h->device);
   h->effective(rows, cols, &rows, &cols);
   int rc = h->makeGeometry(rows, cols);
@@ -962,6 +1005,7 @@ int orbx_extract_batch_device(orbx_t* h, const uint8_t* d_imgs, int nframes, int
     g_err = "step_bytes < cols";
     return -2;
   }
+  EpochScope es(&h->allocEpoch);
   HIP_TRY(hipSetDevice(h->device));
   int er, ec;
   h->effective(rows, cols, &er, &ec);
@@ -984,6 +1028,7 @@ int orbx_extract(orbx_t* h, const uint8_t* img, int rows, int cols, size_t step_
     g_err = "orbx_extract: bad arguments";
     return -2;
   }
+  EpochScope es(&h->allocEpoch);
   HIP_TRY(hipSetDevice(h->device));
   int er, ec;
   h->effective(rows, cols, &er, &ec);
@@ -1005,11 +1050,10 @@ int orbx_extract(orbx_t* h, const uint8_t* img, int rows, int cols, size_t step_
   // Host -> device as ONE linear copy (a pitched copy from pageable memory degenerates to a row-by-row transfer: 3 ms for a
   // 1241-px-wide image), then, if the caller's step is not the 64-byte aligned pitch the kernels like, a device-side repitch.
   // The caller's buffer is pageable: the runtime would stage it through its own pinned chunks with a synchronisation per chunk.
-  // One host memcpy into the handle's pinned buffer and one DMA is shorter (ORBX_NO_PINNED_INPUT=1 restores the direct copy).
+  // One host memcpy into the handle's pinned buffer and one DMA is shorter.
   const size_t rawBytes = (int)step_bytes == pitch ? (size_t)pitch * rows : step_bytes * (size_t)(rows - 1) + cols;
-  static const bool directIn = getenv("ORBX_NO_PINNED_INPUT") != nullptr;
   const uint8_t*    hsrc     = img;
-  if (!directIn && !is_pinned(img)) {  // an image that already lives in pinned memory (orbx_host_alloc) is uploaded from where it is
+  if (!is_pinned(img)) {  // an image that already lives in pinned memory (orbx_host_alloc) is uploaded from where it is
     if (h->hInCap < rawBytes) {
       if (h->hIn) hipHostFree(h->hIn);
       h->hIn = nullptr, h->hInCap = 0;
@@ -1029,6 +1073,13 @@ int orbx_extract(orbx_t* h, const uint8_t* img, int rows, int cols, size_t step_
     HIP_TRY(hipHostMalloc((void**)&h->hOut, outBytes, hipHostMallocDefault));
     h->hOutCap = outBytes;
   }
+  const size_t pyrBytes = h->pyrToHost ? (size_t)h->geom.pyrBytes : 0;  // levels >= 1 ride home behind the records: no extra round trip
+  if (pyrBytes && h->hPyrCap < pyrBytes) {
+    if (h->hPyr) hipHostFree(h->hPyr);
+    h->hPyr = nullptr, h->hPyrCap = 0;
+    HIP_TRY(hipHostMalloc((void**)&h->hPyr, pyrBytes, hipHostMallocDefault));
+    h->hPyrCap = pyrBytes;
+  }
   auto enqueue = [&]() -> int {  // upload, the kernel chain, the three downloads: everything between the host copies in and out
     if ((int)step_bytes == pitch) {
       HIP_TRY(hipMemcpyAsync(h->dStage.p, hsrc, rawBytes, hipMemcpyHostToDevice, h->stream));
@@ -1039,16 +1090,20 @@ int orbx_extract(orbx_t* h, const uint8_t* img, int rows, int cols, size_t step_
     const int rc2 = h->runResized(h->dStage.p, 1, rows, cols, pitch, (size_t)pitch * rows, lap0, lap1, reinterpret_cast<orbx::KpRec*>(dKpP), dDescP, dCountsP, need, h->stream);
     if (rc2) return rc2;
     HIP_TRY(hipMemcpyAsync(h->hOut, h->dOutBlock.p, outBytes, hipMemcpyDeviceToHost, h->stream));
+    if (pyrBytes && h->nlevels > 1) HIP_TRY(hipMemcpyAsync(h->hPyr, h->dPyr.p, pyrBytes, hipMemcpyDeviceToHost, h->stream));
     return 0;
   };
   // Replay form (default; orbx_set_graph_replay(h, 0) / ORBX_GRAPH=0 turn it off): the enqueue sequence of a call is a pure function of this key, so the second
   // call with the same key records it into a hipGraph (stream capture) and later calls replay it with one launch.
   bool done = false;
   if (h->graphReplay && !h->profiling && (rc = h->ensureWorkspace(er, ec, 1))) return rc;  // allocations happen before the key is taken
-  const orbx_extractor::GraphKey key{rows, cols, step_bytes, lap0, lap1, need, hsrc, h->hOut, h->tapMode, h->preW, h->preH, g_allocEpoch.load()};
+  const orbx_extractor::GraphKey key{rows, cols, step_bytes, lap0, lap1, need, hsrc, h->hOut, h->tapMode, h->preW, h->preH, pyrBytes ? h->hPyr : nullptr, h->allocEpoch, g_allocEpochFallback.load()};
   if (h->graphReplay && !h->profiling) {
     if (h->graphExec && key == h->graphKey) {
       HIP_TRY(hipGraphLaunch(h->graphExec, h->stream));
+      // host-side state an eager enqueue leaves behind (run()): level 0 of the pyramid accessors and of orbx_stereo_matches is this call's
+      // staged image again, whatever a batch / async call on the same handle pointed it at in between
+      h->bufs.img0 = h->graphImg0, h->bufs.img0Pitch = h->graphImg0Pitch, h->bufs.img0FrameStride = h->graphImg0Stride, h->lastB = 1;
       done = true;
     } else if (h->graphSeen && key == h->graphKey) {  // seen once eagerly (every allocation has happened): record
       if (h->graphExec) hipGraphExecDestroy(h->graphExec), h->graphExec = nullptr;
@@ -1058,6 +1113,7 @@ int orbx_extract(orbx_t* h, const uint8_t* img, int rows, int cols, size_t step_
         hipError_t e   = hipStreamEndCapture(h->stream, &graph);
         if (rc3 == 0 && e == hipSuccess && graph && hipGraphInstantiate(&h->graphExec, graph, nullptr, nullptr, 0) == hipSuccess) {
           HIP_TRY(hipGraphLaunch(h->graphExec, h->stream));
+          h->graphImg0 = h->bufs.img0, h->graphImg0Pitch = h->bufs.img0Pitch, h->graphImg0Stride = h->bufs.img0FrameStride;  // set by run() during the capture
           done = true;
         } else {
           (void)hipGetLastError();
@@ -1075,6 +1131,7 @@ int orbx_extract(orbx_t* h, const uint8_t* img, int rows, int cols, size_t step_
   }
   if (!done && (rc = enqueue())) return rc;
   HIP_TRY(hipStreamSynchronize(h->stream));
+  h->hPyrValid      = pyrBytes != 0;
   const int* counts = reinterpret_cast<const int*>(h->hOut);
   const int  n      = std::min(counts[0], need);
   if (n > 0) {
@@ -1096,7 +1153,27 @@ void* orbx_host_alloc(size_t bytes) {
 }
 
 void orbx_host_free(void* p) {
-  if (p) hipHostFree(p);
+  if (p && !g_runtimeDown.load()) hipHostFree(p);
+}
+
+// Not part of include/orbx.h: the other translation units ask before they touch the device in their destroy paths, and enrol their
+// handles for the exit handler.
+int orbx_internal_runtime_down(void) { return g_runtimeDown.load() ? 1 : 0; }
+
+void orbx_internal_register(void* obj, void (*release_device)(void*)) {
+  arm_exit_handler();
+  std::lock_guard<std::mutex> lock(live_handles().m);
+  live_handles().v.emplace_back(obj, release_device);
+}
+
+void orbx_internal_unregister(void* obj) {
+  std::lock_guard<std::mutex> lock(live_handles().m);
+  auto& v = live_handles().v;
+  for (size_t i = 0; i < v.size(); i++)
+    if (v[i].first == obj) {
+      v.erase(v.begin() + i);
+      break;
+    }
 }
 
 static bool is_pinned(const void* p) {
@@ -1131,17 +1208,9 @@ static int ensure_pinned(uint8_t** p, size_t* capBytes, size_t need) {
 // Device -> pinned host on `s`: the low-occupancy copy kernel when both ends are 16-byte aligned, else the runtime's copy.
 static int copy_out(hipStream_t s, void* host_dst, const void* dev_src, size_t bytes) {
   if (bytes == 0) return 0;
-  static const int dbgMode = getenv("ORBX_DBG_COPYOUT") ? atoi(getenv("ORBX_DBG_COPYOUT")) : 0;  // diagnosis only: 2 = skip, 3 = copy to device scratch
-  if (dbgMode == 2) return 0;
-  if (dbgMode == 3) {
-    static void* scratch = nullptr;
-    if (!scratch) HIP_TRY(hipMalloc(&scratch, 64 << 20));
-    host_dst = scratch;
-  }
-  if (((reinterpret_cast<uintptr_t>(host_dst) | reinterpret_cast<uintptr_t>(dev_src)) & 15) == 0 && (bytes & 3) == 0 && !getenv("ORBX_RUNTIME_D2H")) {
+  if (((reinterpret_cast<uintptr_t>(host_dst) | reinterpret_cast<uintptr_t>(dev_src)) & 15) == 0 && (bytes & 3) == 0) {
     const long long n16 = (long long)(bytes >> 4);
-    static const int blocks = getenv("ORBX_COPYOUT_BLOCKS") ? std::max(1, atoi(getenv("ORBX_COPYOUT_BLOCKS"))) : orbx::kCopyOutBlocks;
-    hipLaunchKernelGGL(orbx::k_copy_out, dim3(blocks), dim3(256), 0, s, (const orbx::u32x4*)dev_src, (orbx::u32x4*)host_dst, n16, (int)((bytes & 15) >> 2));
+    hipLaunchKernelGGL(orbx::k_copy_out, dim3(orbx::kCopyOutBlocks), dim3(256), 0, s, (const orbx::u32x4*)dev_src, (orbx::u32x4*)host_dst, n16, (int)((bytes & 15) >> 2));
     HIP_TRY(hipGetLastError());
     return 0;
   }
@@ -1182,6 +1251,7 @@ int orbx_extract_async(orbx_t* h, const uint8_t* imgs, int nframes, int rows, in
     g_err = "orbx_extract_async: bad arguments";
     return -2;
   }
+  EpochScope es(&h->allocEpoch);
   HIP_TRY(hipSetDevice(h->device));
   int er, ec;
   h->effective(rows, cols, &er, &ec);
@@ -1191,26 +1261,24 @@ int orbx_extract_async(orbx_t* h, const uint8_t* imgs, int nframes, int rows, in
     g_err = "orbx_extract_async: cap below orbx_max_keypoints()";
     return -2;
   }
-  const int                  t  = h->nextTicket;
-  orbx_extractor::AsyncSlot& sl = h->slots[t % h->asyncDepth];
-  if (sl.ticket >= 0) {
-    g_err = "orbx_extract_async: all slots in flight (orbx_wait the oldest ticket first, or raise orbx_set_async_depth)";
+  const int                  t   = h->nextTicket;
+  orbx_extractor::AsyncSlot* slp = nullptr;  // any free slot: tickets may be waited for in any order
+  for (int i = 0; i < h->asyncDepth && !slp; i++)
+    if (h->slots[(t + i) % h->asyncDepth].ticket < 0) slp = &h->slots[(t + i) % h->asyncDepth];
+  if (!slp) {
+    g_err = "orbx_extract_async: all slots in flight (orbx_wait a ticket first, or raise orbx_set_async_depth)";
     return -2;
   }
+  orbx_extractor::AsyncSlot& sl = *slp;
   if (!h->sIn) {
     HIP_TRY(hipStreamCreateWithFlags(&h->sIn, hipStreamNonBlocking));
     // The copy-out kernels must not share a hardware queue with the extraction kernels: HIP multiplexes its streams onto a few
     // hardware queues (least-referenced first), and two streams on one queue execute in submission order -- measured, the copy-out
     // then ran strictly between orientation and matching instead of beside them.  A stream created with a CU mask always owns a
-    // queue; the mask itself enables every CU (ORBX_COPYOUT_CUS = n restricts the copy-out to the first n CUs of the mask).
+    // queue; the mask itself enables every CU.
     {
-      uint32_t   mask[8];
-      const int  ncu = getenv("ORBX_COPYOUT_CUS") ? atoi(getenv("ORBX_COPYOUT_CUS")) : 256;
-      for (int i = 0; i < 8; i++) {
-        const int lo = 32 * i, n = std::min(std::max(ncu - lo, 0), 32);
-        mask[i] = n >= 32 ? 0xffffffffu : ((1u << n) - 1u);
-      }
-      if (getenv("ORBX_COPYOUT_PLAIN_STREAM") || hipExtStreamCreateWithCUMask(&h->sOut, 8, mask) != hipSuccess) {
+      const uint32_t mask[8] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+      if (hipExtStreamCreateWithCUMask(&h->sOut, 8, mask) != hipSuccess) {
         (void)hipGetLastError();
         HIP_TRY(hipStreamCreateWithFlags(&h->sOut, hipStreamNonBlocking));
       }
@@ -1255,8 +1323,9 @@ int orbx_extract_async(orbx_t* h, const uint8_t* imgs, int nframes, int rows, in
 
 static orbx_extractor::AsyncSlot* find_slot(orbx_t* h, int ticket) {
   if (!h || ticket < 0) return nullptr;
-  orbx_extractor::AsyncSlot& sl = h->slots[ticket % h->asyncDepth];
-  return sl.ticket == ticket ? &sl : nullptr;
+  for (auto& sl : h->slots)
+    if (sl.ticket == ticket) return &sl;
+  return nullptr;
 }
 
 int orbx_async_device_buffers(orbx_t* h, int ticket, const orbx_keypoint_t** d_kps, const uint8_t** d_desc, const int** d_counts, void** stream) {
@@ -1305,6 +1374,11 @@ int orbx_wait(orbx_t* h, int ticket) {
     g_err = "orbx_wait: unknown ticket";
     return -2;
   }
+  // whatever happens below, the ticket is over: a slot that stayed reserved after an error would be lost for good
+  struct Release {
+    orbx_extractor::AsyncSlot* sl;
+    ~Release() { sl->ticket = -1, sl->pendingOut = false; }
+  } release{sl};
   HIP_TRY(hipSetDevice(h->device));
   int rc = flush_copy_out(h, *sl);
   if (rc) return rc;
@@ -1315,7 +1389,6 @@ int orbx_wait(orbx_t* h, int ticket) {
     memcpy(sl->uDesc, sl->hOut + kpBytes, dBytes);
     memcpy(sl->uCounts, sl->hOut + kpBytes + dBytes, (size_t)sl->nframes * 2 * sizeof(int));
   }
-  sl->ticket = -1;
   return 0;
 }
 
@@ -1334,6 +1407,13 @@ int orbx_pyramid_level(orbx_t* h, int frame, int level, uint8_t* dst, size_t dst
   const orbx::LevelGeom& L = h->geom.lv[level];
   if (level == 0)
     return copy_level(h, h->bufs.img0 + (long long)frame * h->bufs.img0FrameStride, h->bufs.img0Pitch, L.w, L.h, dst, dst_step, rows, cols);
+  if (h->hPyrValid && frame == 0) {  // orbx_set_pyramid_download: the level already lies in host memory, no device call
+    if (rows) *rows = L.h;
+    if (cols) *cols = L.w;
+    if (dst)
+      for (int r = 0; r < L.h; r++) memcpy(dst + (size_t)r * dst_step, h->hPyr + L.pyrOff + (size_t)r * L.pitch, (size_t)L.w);
+    return 0;
+  }
   return copy_level(h, h->bufs.pyr + (long long)frame * h->geom.pyrBytes + L.pyrOff, L.pitch, L.w, L.h, dst, dst_step, rows, cols);
 }
 
@@ -1371,6 +1451,8 @@ int orbx_debug_level_keypoints(orbx_t* h, int frame, int level, uint32_t* out, i
 int orbx_debug_octree_device(orbx_t* h, const uint32_t* cand, int n, int W, int H, int N, uint32_t* out, int* out_count) {
   using namespace orbx;
   if (!h || n < 0 || W <= 0 || H <= 0 || N < 0) return -2;
+  unsigned long long scratchEpoch = 0;  // the temporaries below are not the handle's: they retire nobody's graph
+  EpochScope         es(&scratchEpoch);
   HIP_TRY(hipSetDevice(h->device));
   const int nIni = (int)std::round((float)W / (float)H);
   if (nIni <= 0) return -2;
@@ -1454,6 +1536,7 @@ int orbx_undistort_keypoints_device(orbx_t* h, const orbx_keypoint_t* d_kps, con
 int orbx_undistort_keypoints(orbx_t* h, const orbx_keypoint_t* kps, int n, const float K[4], const float* dist, int ndist, orbx_keypoint_t* out) {
   if (!h || n < 0 || (n > 0 && (!kps || !out)) || !K) return -2;
   if (n == 0) return 0;
+  EpochScope es(&h->allocEpoch);
   HIP_TRY(hipSetDevice(h->device));
   if (h->dKpOut.ensure((size_t)2 * n)) return -3;
   HIP_TRY(hipMemcpyAsync(h->dKpOut.p, kps, (size_t)n * sizeof(orbx_keypoint_t), hipMemcpyHostToDevice, h->stream));
@@ -1483,6 +1566,7 @@ int orbx_stereo_matches(orbx_t* left, orbx_t* right, const orbx_keypoint_t* kl, 
     return -2;
   }
   if (nl == 0) return 0;
+  EpochScope es(&left->allocEpoch);
   HIP_TRY(hipSetDevice(left->device));
   HIP_TRY(hipStreamSynchronize(right->stream));
   hipStream_t      s = left->stream;
@@ -1547,6 +1631,7 @@ int orbx_stereo_matches_batch_device(orbx_t* left, orbx_t* right, const orbx_key
     return -2;
   }
   if (nframes == 0) return 0;
+  EpochScope es(&left->allocEpoch);
   HIP_TRY(hipSetDevice(left->device));
   const bool byRow = left->geom.rows <= kStereoMaxRows;
   if (left->dStereoSad.ensure((size_t)nframes * cap) ||
@@ -1573,6 +1658,8 @@ int orbx_stereo_matches_batch_device(orbx_t* left, orbx_t* right, const orbx_key
 // PMC calibration hook (see k_calib_read): reads `nbytes` of a scratch buffer with `width` bytes per lane per load.
 int orbx_debug_calib_read(orbx_t* h, long long nbytes, int width) {
   if (!h || nbytes <= 0 || (width != 1 && width != 4 && width != 16)) return -2;
+  unsigned long long scratchEpoch = 0;
+  EpochScope         es(&scratchEpoch);
   HIP_TRY(hipSetDevice(h->device));
   DevBuf<uint8_t>  buf;
   DevBuf<unsigned> sink;

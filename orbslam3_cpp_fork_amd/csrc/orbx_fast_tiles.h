@@ -33,7 +33,6 @@ struct FastTile {  // host-built (orbx_extractor::makeGeometry), read with scala
 
 struct FastLds2 {  // dynamic LDS plan (bytes); the pixel tile sits at offset 16
   int scoreOff, scoreBytes, candOff, candCap, mask1Off, mask2Off, cntOff, total;
-  int stageOff, listCOff, listCCap;  // two-stage form: 4 x 128 u16 staging entries (one slice per wave), list of scored corners for NMS
 };
 
 constexpr int kFastTileThreads = 256;
@@ -49,29 +48,9 @@ __device__ __forceinline__ pk16 pair_at(uint32_t w0, uint32_t w1, uint32_t w2) {
   return pk_from(__builtin_amdgcn_perm(hi, lo, sel));
 }
 
-// Exact corner score with a runtime LDS pitch (see fast_score_pm in orbx_kernels.h for the arithmetic).
-__device__ __forceinline__ int fast_score_pm_rt(const uint8_t* __restrict__ c, int P) {
-  const uint8_t *r1 = c + P, *r2 = r1 + P, *r3 = r2 + P, *q1 = c - P, *q2 = q1 - P, *q3 = q2 - P;
-  const int  pv[16] = {r3[0], r3[1], r2[2], r1[3], c[3], q1[3], q2[2], q3[1], q3[0], q3[-1], q2[-2], q1[-3], c[-3], r1[-3], r2[-2], r3[-1]};
-  const int  v0 = c[0];
-  const pk16 vv = pk_pair(v0, 0x10000 - v0);  // (v, -v)
-  pk16       e[16];
-#pragma unroll
-  for (int k = 0; k < 16; k++) e[k] = vv - pk_pair(pv[k], 0x10000 - pv[k]);  // (v - p, p - v)
-  pk16 m2[16], m4[16];
-#pragma unroll
-  for (int i = 0; i < 16; i++) m2[i] = pk_min(e[i], e[(i + 1) & 15]);
-#pragma unroll
-  for (int i = 0; i < 16; i++) m4[i] = pk_min(m2[i], m2[(i + 2) & 15]);
-  pk16 A = pk_pair(0xfc18, 0xfc18);  // -1000
-#pragma unroll
-  for (int i = 0; i < 16; i++) A = pk_max(A, pk_min(pk_min(m4[i], m4[(i + 4) & 15]), e[(i + 8) & 15]));
-  return max((int)A.x, (int)A.y) - 1;
-}
-
-template <bool AL4, bool TWO_STAGE>
+template <bool AL4>
 __global__ __launch_bounds__(kFastTileThreads) void k_fast_tiles(Bufs b, FrameGeom g, const FastTile* __restrict__ tiles, const int* __restrict__ order,
-                                                                  int iniTh, int minTh, FastLds2 fl, int dbgSkip) {
+                                                                  int iniTh, int minTh, FastLds2 fl, int dbgSkip) {  // dbgSkip: phase ablation, only read in -DORBX_TUNING builds
   extern __shared__ __align__(16) uint8_t fastLds2[];
   const int tix = order[blockIdx.x];
   if (tix < 0) return;
@@ -83,8 +62,7 @@ __global__ __launch_bounds__(kFastTileThreads) void k_fast_tiles(Bufs b, FrameGe
   unsigned short* cand = reinterpret_cast<unsigned short*>(fastLds2 + fl.candOff);
   uint32_t*      mask1 = reinterpret_cast<uint32_t*>(fastLds2 + fl.mask1Off);
   uint32_t*      mask2 = reinterpret_cast<uint32_t*>(fastLds2 + fl.mask2Off);
-  int*           cnt   = reinterpret_cast<int*>(fastLds2 + fl.cntOff);  // [0] candidates, [1 + c] iniTh winners of cell c, [1 + ncells] list C
-  unsigned short* listC = reinterpret_cast<unsigned short*>(fastLds2 + fl.listCOff);
+  int*           cnt   = reinterpret_cast<int*>(fastLds2 + fl.cntOff);  // [0] candidates, [1 + c] iniTh winners of cell c
   const int      P     = T.ldsPitch;
   const int      lowTh = max(min(iniTh, minTh), 1);
 
@@ -131,7 +109,7 @@ __global__ __launch_bounds__(kFastTileThreads) void k_fast_tiles(Bufs b, FrameGe
     for (int i = tid * 16, n = min(fl.scoreBytes, (T.th * P + 15) & ~15); i < n; i += kFastTileThreads * 16) *reinterpret_cast<uint4*>(score + i) = make_uint4(0, 0, 0, 0);
     const int nmask = T.ncells * T.W;
     for (int i = tid; i < nmask; i += kFastTileThreads) mask1[i] = 0, mask2[i] = 0;
-    if (tid <= T.ncells + 1) cnt[tid] = 0;
+    if (tid <= T.ncells) cnt[tid] = 0;
   }
   __syncthreads();
 
@@ -144,7 +122,10 @@ __global__ __launch_bounds__(kFastTileThreads) void k_fast_tiles(Bufs b, FrameGe
   const int      glast  = T.g0 + T.NG - 1;
   const uint32_t mFirst = 0xfu & ~((1u << (T.ox3 & 3)) - 1u);                      // pixels of the first group that are interior
   const uint32_t mLast  = (1u << (((T.ox3 + T.IW - 1) & 3) + 1)) - 1u;             // ... of the last group
-  for (int it = 0; it < ((dbgSkip & 1) ? 0 : npass); it++) {  // dbgSkip: ablation switches for tuning (ORBX_DBG_SKIP_FAST)
+#ifdef ORBX_TUNING
+  if (dbgSkip & 1) return;
+#endif
+  for (int it = 0; it < npass; it++) {
     const int item = tid + kFastTileThreads * it;
     if (item < T.nitems) {
       const int      row = div_magic(item, T.mNG), gg = item - row * T.NG + T.g0;
@@ -152,21 +133,6 @@ __global__ __launch_bounds__(kFastTileThreads) void k_fast_tiles(Bufs b, FrameGe
       const uint32_t top = *reinterpret_cast<const uint32_t*>(A - P3), bot = *reinterpret_cast<const uint32_t*>(A + P3);
       const uint32_t m0 = *reinterpret_cast<const uint32_t*>(A - 4), m1 = *reinterpret_cast<const uint32_t*>(A), m2 = *reinterpret_cast<const uint32_t*>(A + 4);
       uint32_t       neg[2];
-      if (TWO_STAGE) {
-        // dense stage: the N-S and E-W opposite pairs only (5 dwords, 10 cuts, 12 packed min / max per 4 px); 8.9 % of the bench
-        // stream's pixels survive, the two diagonal pairs are tested on the compacted survivors (stage 2, below)
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-          pk16 v, n, sth, ea, we;
-          if (h == 0) {
-            v = pair_at<4>(m0, m1, m2), n = pair_at<4>(0, bot, 0), sth = pair_at<4>(0, top, 0), ea = pair_at<7>(m0, m1, m2), we = pair_at<1>(m0, m1, m2);
-          } else {
-            v = pair_at<6>(m0, m1, m2), n = pair_at<6>(0, bot, 0), sth = pair_at<6>(0, top, 0), ea = pair_at<9>(m0, m1, m2), we = pair_at<3>(m0, m1, m2);
-          }
-          const pk16 dmin = pk_max(pk_min(n, sth), pk_min(ea, we)), bmax = pk_min(pk_max(n, sth), pk_max(ea, we));
-          neg[h]          = pk_bits(tpk - pk_max(v - dmin, bmax - v));
-        }
-      } else {
       const uint32_t u0 = *reinterpret_cast<const uint32_t*>(A - P2 - 4), u1 = *reinterpret_cast<const uint32_t*>(A - P2),
                      u2 = *reinterpret_cast<const uint32_t*>(A - P2 + 4);
       const uint32_t d0 = *reinterpret_cast<const uint32_t*>(A + P2 - 4), d1 = *reinterpret_cast<const uint32_t*>(A + P2),
@@ -195,7 +161,6 @@ __global__ __launch_bounds__(kFastTileThreads) void k_fast_tiles(Bufs b, FrameGe
         }
         // passes iff dmin < v - t or bmax > v + t  <=>  max(v - dmin, bmax - v) > t  <=>  t - max(...) < 0
         neg[h] = pk_bits(tpk - pk_max(v - dmin, bmax - v));
-      }
       }
       // sign bits (15 / 31 of neg[0], neg[1]) -> 4-bit nibble; the first / last group's pixels outside the interior are masked off
       const uint32_t sb  = __builtin_amdgcn_perm(neg[1], neg[0], 0x07050301u);           // bytes: px0, px1, px2, px3 (bit 7 each)
@@ -229,67 +194,16 @@ __global__ __launch_bounds__(kFastTileThreads) void k_fast_tiles(Bufs b, FrameGe
   __syncthreads();
 
   // ---- S3: exact score of the candidates
-  const int ncand = (dbgSkip & 2) ? 0 : min(cnt[0], fl.candCap);
+#ifdef ORBX_TUNING
+  if (dbgSkip & 2) return;
+#endif
+  const int ncand = min(cnt[0], fl.candCap);
   auto      score_one = [&](int row, int col) {
-    const int o  = (row + 3) * P + col;
-    const int sc = fast_score_pm_rt(tile + o, P);
-    score[o]     = (uint8_t)(sc >= lowTh ? sc : 0);  // scores below both thresholds are never corners
+    const int o = (row + 3) * P + col;
+    int       s0, s1;
+    fast_score2(tile + o, tile + o, P, &s0, &s1);
+    score[o] = (uint8_t)(s0 >= lowTh ? s0 : 0);  // scores below both thresholds are never corners
   };
-  // Stage 2 of the pre-test on one candidate: all four opposite pairs (9 byte reads, plain 32-bit min / max).
-  auto stage2 = [&](int row, int col) -> bool {
-    const uint8_t* c = tile + ((row + 3) * P + col);
-    const int v = c[0];
-    const int a0 = c[P3], a4 = c[-P3], a1 = c[P2 + 2], a5 = c[-P2 - 2], a2 = c[3], a6 = c[-3], a3 = c[-P2 + 2], a7 = c[P2 - 2];
-    const int dmin = max(max(min(a0, a4), min(a1, a5)), max(min(a2, a6), min(a3, a7)));
-    const int bmax = min(min(max(a0, a4), max(a1, a5)), min(max(a2, a6), max(a3, a7)));
-    return dmin < v - lowTh || bmax > v + lowTh;
-  };
-  // exact score of one candidate (all lanes call it; inactive lanes contribute nothing) + the list of scored corners for the NMS pass
-  auto score_rec = [&](unsigned e, bool active) {
-    int sc = 0;
-    if (active) {
-      const int o = ((int)(e >> 9) + 3) * P + (int)(e & 511u);
-      sc          = fast_score_pm_rt(tile + o, P);
-      sc          = sc >= lowTh ? sc : 0;
-      score[o]    = (uint8_t)sc;
-    }
-    const unsigned long long hb = __ballot(sc > 0);
-    if (hb) {
-      int base = 0;
-      if (lane == 0) base = atomicAdd(&cnt[1 + T.ncells], __popcll(hb));
-      base = __shfl(base, 0, 64);
-      const int idx = base + __popcll(hb & ((1ull << lane) - 1ull));
-      if (sc > 0 && idx < fl.listCCap) listC[idx] = (unsigned short)e;
-    }
-  };
-  if (TWO_STAGE) {
-    // every wave streams its 64-entry slices of the stage-1 list, tests stage 2, and batches the survivors in its own staging
-    // slice until a full wave of them can be scored: the 134-instruction score always runs with (nearly) all lanes busy
-    unsigned short* stg  = reinterpret_cast<unsigned short*>(fastLds2 + fl.stageOff) + wave * 128;
-    int             fill = 0;
-    for (int k0 = wave * 64; k0 < ncand; k0 += kFastTileThreads) {
-      const int      k = k0 + lane;
-      const unsigned e = k < ncand ? cand[k] : 0xffffu;
-      const bool     pass = e != 0xffffu && stage2((int)(e >> 9), (int)(e & 511u));
-      const unsigned long long pb = __ballot(pass);
-      if (pass) stg[fill + __popcll(pb & ((1ull << lane) - 1ull))] = (unsigned short)e;
-      fill += __popcll(pb);
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      if (fill >= 64) {
-        const unsigned e2 = stg[lane];
-        score_rec(e2, true);
-        const unsigned rest = stg[64 + lane];
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        fill -= 64;
-        if (lane < fill) stg[lane] = (unsigned short)rest;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-      }
-    }
-    if (fill > 0) score_rec(lane < fill ? stg[lane] : 0xffffu, lane < fill);
-  } else {
   // two listed candidates per lane: the two-pixel form of the score (both pixels' margins in the halves of one register, a min chain
   // and a max chain) costs ~96 vector instructions per pixel against ~134 for the one-pixel, both-polarities form
   for (int j = tid; 2 * j < ncand; j += kFastTileThreads) {
@@ -304,7 +218,6 @@ __global__ __launch_bounds__(kFastTileThreads) void k_fast_tiles(Bufs b, FrameGe
       if (v1) score[o1] = (uint8_t)(s1 >= lowTh ? s1 : 0);
     }
   }
-  }
   if (__ballot(ovf != 0)) {
     unsigned long long m = ovf;
     while (m) {
@@ -312,12 +225,14 @@ __global__ __launch_bounds__(kFastTileThreads) void k_fast_tiles(Bufs b, FrameGe
       m &= m - 1;
       const int item = tid + kFastTileThreads * (bi >> 2);
       const int row = div_magic(item, T.mNG), col = (item - row * T.NG + T.g0) * 4 + (bi & 3);
-      if (!TWO_STAGE || stage2(row, col)) score_one(row, col);
+      score_one(row, col);
     }
   }
   __syncthreads();
 
+#ifdef ORBX_TUNING
   if (dbgSkip & 4) return;
+#endif
   // ---- S4: strict 3x3 NMS under both thresholds inside the candidate's own cell
   auto nms_one = [&](int row, int col) {
     const int o = (row + 3) * P + col;
@@ -351,17 +266,9 @@ __global__ __launch_bounds__(kFastTileThreads) void k_fast_tiles(Bufs b, FrameGe
       if (f2) atomicOr(&mask2[w], bit);
     }
   };
-  const int nC = TWO_STAGE ? cnt[1 + T.ncells] : fl.listCCap + 1;
-  if (nC <= fl.listCCap) {  // the scored corners (score > 0) were all listed: ~40 % of the candidates, ~25 % of the stage-1 list
-    for (int k = tid; k < nC; k += kFastTileThreads) {
-      const unsigned e = listC[k];
-      nms_one((int)(e >> 9), (int)(e & 511u));
-    }
-  } else {
-    for (int k = tid; k < ncand; k += kFastTileThreads) {
-      const unsigned e = cand[k];
-      if (e != 0xffffu) nms_one((int)(e >> 9), (int)(e & 511u));
-    }
+  for (int k = tid; k < ncand; k += kFastTileThreads) {
+    const unsigned e = cand[k];
+    if (e != 0xffffu) nms_one((int)(e >> 9), (int)(e & 511u));
   }
   if (__ballot(ovf != 0)) {
     unsigned long long m = ovf;

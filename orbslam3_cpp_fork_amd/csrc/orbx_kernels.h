@@ -2,7 +2,7 @@
 //
 // Stage map (reference function -> kernel):
 //   ComputePyramid            src/ORBextractor.cc:1140-1173 -> k_resize_level   (one launch per level >= 1)
-//   cv::FAST per cell         :800-839                      -> k_fast_cells     (one workgroup per cell)
+//   cv::FAST per cell         :800-839                      -> k_fast_tiles     (one workgroup per run of adjacent cells, orbx_fast_tiles.h)
 //   DistributeOctTree         :556-753                      -> k_octree         (one workgroup per frame x level)
 //   operator() output order   :1115-1134                    -> k_layout         (one workgroup per frame)
 //   cv::GaussianBlur 7x7      :1103-1104                    -> k_blur_levels    (64x16 tiles, all levels)
@@ -39,8 +39,6 @@ struct Bufs {
   const int2*    xtab;  // resize tables: .x = source index, .y = a0 | a1 << 16 (Q11)
   const int2*    ytab;
   const int*     cellSlot;   // [totalCells] slot base of each cell inside the frame's slot array
-  const int*     cellOrder;  // [fastGrid] XCD-aware launch order of the FAST cells (-1 = padding)
-  const int4*    cellDesc;   // [fastGrid][3] pre-decoded cell geometry for that order (see fast_decode)
   uint32_t*      slots;      // [B][totalSlots] per-cell candidate slots written by FAST
   int*           cellCount;  // [B][totalCells]
   // quadtree workspace, per frame: point arrays [totalSlots], node arrays [totalNodes]
@@ -71,6 +69,9 @@ __device__ __forceinline__ const uint8_t* level_raw(const Bufs& b, const FrameGe
   *pitch = g.lv[level].pitch;
   return b.pyr + (long long)f * g.pyrBytes + g.lv[level].pyrOff;
 }
+
+// idx / d with one multiply-high, m = floor(2^32 / d) + 1: exact whenever idx * d < 2^32 (every use here: idx < 65536, d < 65536).
+__device__ __forceinline__ int div_magic(unsigned idx, unsigned m) { return m ? (int)__umulhi(idx, m) : (int)idx; }  // m == 0 encodes d == 1
 
 // ------------------------------------------------------------------------------------------------
 // ComputePyramid: cv::resize(INTER_LINEAR) 8UC1 fixed point (OpenCV resize.cpp).
@@ -191,6 +192,113 @@ __global__ __launch_bounds__(256) void k_resize_level(Bufs b, FrameGeom g, int l
                      blockIdx.x >> 3, blockIdx.y);
 }
 
+// ------------------------------------------------------------------------------------------------
+// ComputePyramid, several levels in ONE launch -- the latency form of the chain (src/ORBextractor.cc:1140-1173: each level is resized from
+// the previous one, so the chain itself cannot go, but for a handful of frames it need not be a chain of seven launches, each of which
+// pays a dispatch gap for a few microseconds of work).  A workgroup owns a BAND of rows of level endLevel - 1 and walks levels
+// firstLevel .. endLevel - 1 inside LDS: it stages the rows of level firstLevel - 1 its band descends from, together with the x tables of
+// the levels and its own slices of the y tables (ONE exposure to global-memory latency), produces its rows of every level from the previous
+// level's rows in LDS, and writes the rows it OWNS of every level to the pyramid block.  Rows a neighbouring band needs as well (1-2 per
+// level boundary, accumulating downwards) are computed by both and written by one, so bands never wait for each other.  Row ranges are
+// host-built (PyrBand) from the same tables the per-level kernel reads; the arithmetic is resize_tile's.
+// Batches keep one launch per level: there every launch fills the chip, the step is bound by instruction issue, and the rows computed
+// twice would cost more than the six dispatch gaps saved (measured: 243.6 -> 243.3 k frames/s with levels 4-7 fused).
+// ------------------------------------------------------------------------------------------------
+struct PyrBand {  // rows [lo, lo + n) of level l are computed, [ownLo, ownLo + ownN) written; entry firstLevel - 1 = the staged source rows
+  short lo[kMaxLevels], n[kMaxLevels], ownLo[kMaxLevels], ownN[kMaxLevels];
+};
+
+struct PyrPlan {  // by value to the kernel
+  int      firstLevel, endLevel, nbands;
+  int      ldsHalf;               // bytes of each of the two LDS row buffers
+  int      xtLds, ytLds;          // byte offsets of the staged x / y tables behind them
+  int      xtOff[kMaxLevels];     // first entry of level l's x table in the staged copy (4 * ceil(w / 4) entries, the last one repeated)
+  unsigned quadMagic[kMaxLevels]; // div_magic divider of ceil(w_l / 4)
+};
+
+constexpr int kPyrBandThreads = 1024;
+
+template <bool AL4>
+__global__ __launch_bounds__(kPyrBandThreads) void k_pyramid_bands(Bufs b, FrameGeom g, const PyrBand* __restrict__ bands, PyrPlan plan, int nframes) {
+  extern __shared__ __align__(16) uint8_t pyrLds[];
+  constexpr int NT = kPyrBandThreads;
+  const int     f  = blockIdx.y;
+  const PyrBand& bd  = bands[blockIdx.x];
+  const int      tid = threadIdx.x;
+  uint8_t*       buf[2] = {pyrLds, pyrLds + plan.ldsHalf};
+  int2*          xtL = reinterpret_cast<int2*>(pyrLds + plan.xtLds);
+  int2*          ytL = reinterpret_cast<int2*>(pyrLds + plan.ytLds);
+  // ---- stage: source rows (level firstLevel - 1) with aligned dwords, the x tables, this band's y-table slices
+  {
+    const int        sl = plan.firstLevel - 1;
+    const LevelGeom& Ls = g.lv[sl];
+    int              sp;
+    const uint8_t*   S   = level_raw(b, g, sl, f, &sp) + (long long)bd.lo[sl] * sp;
+    const int        P   = (Ls.w + 3) & ~3, nw4 = P >> 2, items = bd.n[sl] * nw4;
+    const unsigned   mq  = plan.quadMagic[sl];
+    for (int it = tid; it < items; it += NT) {
+      const int r = div_magic(it, mq), c = (it - r * nw4) * 4;
+      uint32_t  v;
+      if (AL4 || sl > 0) {
+        v = *reinterpret_cast<const uint32_t*>(S + (unsigned)(r * sp + c));  // may run past w inside the aligned row
+      } else {
+        const uint8_t* p = S + (unsigned)(r * sp);
+        v = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) v |= (uint32_t)p[min(c + k, Ls.w - 1)] << (8 * k);
+      }
+      *reinterpret_cast<uint32_t*>(buf[0] + r * P + c) = v;
+    }
+    int yo = 0;
+    for (int l = plan.firstLevel; l < plan.endLevel; l++) {
+      const LevelGeom& L  = g.lv[l];
+      const int        n4 = ((L.w + 3) >> 2) * 4;
+      for (int i = tid; i < n4; i += NT) xtL[plan.xtOff[l] + i] = b.xtab[L.xtabOff + min(i, L.w - 1)];
+      for (int i = tid; i < bd.n[l]; i += NT) ytL[yo + i] = b.ytab[L.ytabOff + bd.lo[l] + i];
+      yo += bd.n[l];
+    }
+  }
+  __syncthreads();
+  uint8_t* pyrF = b.pyr + (long long)f * g.pyrBytes;
+  int      yo   = 0;
+  for (int l = plan.firstLevel; l < plan.endLevel; l++) {
+    const LevelGeom& L    = g.lv[l];
+    const uint8_t*   S    = buf[(l - plan.firstLevel) & 1];
+    uint8_t*         D    = buf[(l - plan.firstLevel + 1) & 1];
+    const int        SP   = (g.lv[l - 1].w + 3) & ~3, DP = (L.w + 3) & ~3, nx = DP >> 2;
+    const int        sLo  = bd.lo[l - 1], dLo = bd.lo[l], items = bd.n[l] * nx;
+    const int        oLo  = bd.ownLo[l], oHi = oLo + bd.ownN[l];
+    const int2*      xt4  = xtL + plan.xtOff[l];
+    const int2*      ytB  = ytL + yo;
+    const unsigned   mq   = plan.quadMagic[l];
+    const bool       last = l == plan.endLevel - 1;
+    for (int it = tid; it < items; it += NT) {
+      const int  r = div_magic(it, mq), dx = (it - r * nx) * 4, dy = dLo + r;
+      const int2 yt = ytB[r];
+      const int  r0 = yt.x - sLo;  // the pyramid only shrinks: source row yt.x + 1 exists (see resize_tile) and lies in the staged band
+      const int  b0 = (short)(yt.y & 0xffff), b1 = yt.y >> 16;
+      const uint8_t* s0 = S + r0 * SP;
+      uint32_t       out = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int2 xt = xt4[dx + k];
+        const int  a0 = (short)(xt.y & 0xffff), a1 = xt.y >> 16;
+        int        c = xt.x, c1 = c + 1;
+        asm volatile("" : "+v"(c1));  // byte reads on purpose: a fused ds_read_u16 at an odd address runs at a sixteenth of the speed
+        const int h0 = s0[c] * a0 + s0[c1] * a1;
+        const int h1 = s0[SP + c] * a0 + s0[SP + c1] * a1;
+        const int v  = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+        out |= (uint32_t)(v & 0xff) << (8 * k);
+      }
+      if (!last) *reinterpret_cast<uint32_t*>(D + r * DP + dx) = out;
+      // the level's pitch is a multiple of 64: lanes past w write into the row's padding
+      if (dy >= oLo && dy < oHi) *reinterpret_cast<uint32_t*>(pyrF + L.pyrOff + (unsigned)(dy * L.pitch + dx)) = out;
+    }
+    yo += bd.n[l];
+    __syncthreads();
+  }
+}
+
 // cv::resize(im, im, cv::Size(newWidth, newHeight)) of System::TrackMonocular / TrackStereo / TrackRGBD (src/System.cc:472-478 and
 // siblings) before the extractor sees the image: same arithmetic, any size pair.
 __global__ __launch_bounds__(256) void k_resize_input(const uint8_t* __restrict__ src, int sp, long long srcFrameStride, int sw, int sh,
@@ -218,50 +326,6 @@ __device__ __forceinline__ int xcd_item(int block, int nitems) {
   const int per  = (nitems + 7) >> 3;
   const int item = (block & 7) * per + (block >> 3);
   return ((block >> 3) < per && item < nitems) ? item : -1;
-}
-
-// idx / d for 0 <= idx < 65536, 1 <= d <= 256 with one multiply-high: m = floor(2^32 / d) + 1.
-__device__ __forceinline__ int div_magic(unsigned idx, unsigned m) { return m ? (int)__umulhi(idx, m) : (int)idx; }  // m == 0 encodes d == 1
-
-__device__ __forceinline__ int fast_score(const uint8_t (*tile)[kFastTileMax], int x, int y) {
-  const int v = tile[y][x];
-  int       d[16];
-  d[0]  = v - tile[y + 3][x];
-  d[1]  = v - tile[y + 3][x + 1];
-  d[2]  = v - tile[y + 2][x + 2];
-  d[3]  = v - tile[y + 1][x + 3];
-  d[4]  = v - tile[y][x + 3];
-  d[5]  = v - tile[y - 1][x + 3];
-  d[6]  = v - tile[y - 2][x + 2];
-  d[7]  = v - tile[y - 3][x + 1];
-  d[8]  = v - tile[y - 3][x];
-  d[9]  = v - tile[y - 3][x - 1];
-  d[10] = v - tile[y - 2][x - 2];
-  d[11] = v - tile[y - 1][x - 3];
-  d[12] = v - tile[y][x - 3];
-  d[13] = v - tile[y + 1][x - 3];
-  d[14] = v - tile[y + 2][x - 2];
-  d[15] = v - tile[y + 3][x - 1];
-  int mn2[16], mx2[16], mn4[16], mx4[16];
-#pragma unroll
-  for (int i = 0; i < 16; i++) {
-    mn2[i] = min(d[i], d[(i + 1) & 15]);
-    mx2[i] = max(d[i], d[(i + 1) & 15]);
-  }
-#pragma unroll
-  for (int i = 0; i < 16; i++) {
-    mn4[i] = min(mn2[i], mn2[(i + 2) & 15]);
-    mx4[i] = max(mx2[i], mx2[(i + 2) & 15]);
-  }
-  int A = -1000, Bm = 1000;
-#pragma unroll
-  for (int i = 0; i < 16; i++) {
-    const int m9 = min(min(mn4[i], mn4[(i + 4) & 15]), d[(i + 8) & 15]);
-    const int M9 = max(max(mx4[i], mx4[(i + 4) & 15]), d[(i + 8) & 15]);
-    A            = max(A, m9);
-    Bm           = min(Bm, M9);
-  }
-  return max(A, -Bm) - 1;
 }
 
 // ---- packed 16-bit lanes: two pixels per VGPR (v_pk_min_i16 / v_pk_max_i16 / v_pk_sub_i16) ----------------------
@@ -303,308 +367,6 @@ __device__ __forceinline__ void fast_score2(const uint8_t* __restrict__ cA, cons
   const pk16 sc = pk_max(A, -Bm) - pk16{1, 1};
   *sA           = sc.x;
   *sB           = sc.y;
-}
-
-// Corner score of ONE pixel with both polarities packed: low half d = v - p, high half -d.  min over an arc of the low
-// halves is the dark-arc margin, of the high halves the bright-arc margin, so one chain of packed mins serves both and
-// score = max(low, high of the max over the 16 arcs) - 1.  Half the live registers of the two-pixel form.
-__device__ __forceinline__ int fast_score_pm(const uint8_t* __restrict__ c, int ts) {
-  const int off[16] = {3 * ts,      3 * ts + 1,  2 * ts + 2,  ts + 3, 3, -ts + 3, -2 * ts + 2, -3 * ts + 1,
-                       -3 * ts,     -3 * ts - 1, -2 * ts - 2, -ts - 3, -3, ts - 3,  2 * ts - 2,  3 * ts - 1};
-  const int  v0 = c[0];
-  const pk16 vv = pk_pair(v0, 0x10000 - v0);  // (v, -v)
-  pk16       e[16];
-#pragma unroll
-  for (int k = 0; k < 16; k++) {
-    const int pk = c[off[k]];
-    e[k]         = vv - pk_pair(pk, 0x10000 - pk);  // (v - p, p - v)
-  }
-  pk16 m2[16], m4[16];
-#pragma unroll
-  for (int i = 0; i < 16; i++) m2[i] = pk_min(e[i], e[(i + 1) & 15]);
-#pragma unroll
-  for (int i = 0; i < 16; i++) m4[i] = pk_min(m2[i], m2[(i + 2) & 15]);
-  pk16 A = pk_pair(0xfc18, 0xfc18);  // -1000
-#pragma unroll
-  for (int i = 0; i < 16; i++) A = pk_max(A, pk_min(pk_min(m4[i], m4[(i + 4) & 15]), e[(i + 8) & 15]));
-  return max((int)A.x, (int)A.y) - 1;
-}
-
-// Workgroup barrier that waits for this wave's LDS traffic only.  __syncthreads() also drains vmcnt, which would
-// stall every wave on the next cell's prefetch loads at the first barrier after they were issued.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-constexpr int kFastCellsPerBlock = 1;  // cells walked by one (persistent) workgroup
-constexpr int kFastThreads       = 128;  // workgroup of k_fast_cells
-constexpr int kFastPrefetchMax   = 20;   // row steps of the staging map for the largest tile (80 rows, 4 rows per step)
-constexpr int kFastSmallPre      = 8;    // ... for the 52-byte-stride instantiation (up to 64 rows, 8 rows per step)
-
-struct FastCell {
-  bool           valid;  // false: padding slot or a cell the reference skips (:782-793) / that has no interior
-  int            cell, level, ci_i, ci_j, tw, th, iw, ih, pitch, n4, tw4;
-  int            ox;  // the tile is staged from the 4-byte aligned column below iniX: cell column x sits at LDS column x + ox
-  unsigned       mT4, mIw;
-  const uint8_t* img;  // row 0 of the tile at the ALIGNED column (AL4) / at iniX (byte path, ox = 0)
-};
-
-// Host-built descriptor of one order slot (three int4, scalar loads):
-//   d0 = {cell (-1 = padding), level, iniX | iniY << 16, tw | th << 8 | valid << 16}
-//   d1 = {x offset | y offset << 16 of the cell inside the level (ci_j * wCell, ci_i * hCell),
-//         first candidate slot of the cell inside the frame's slot array, byte offset of (iniX, iniY) inside the
-//         frame's pyramid block (levels >= 1), row pitch (levels >= 1)}
-//   d2 = {div_magic dividers: tile dwords per row (aligned staging), the same for byte staging, interior width; 0}
-// It replaces a per-cell walk over FrameGeom::lv[] (a chain of dependent scalar loads) done twice per cell.
-template <bool AL4>
-__device__ __forceinline__ FastCell fast_decode(const Bufs& b, const FrameGeom& g, int slot, int nslots, int f, int* xoff, int* yoff,
-                                                int* slotOff) {
-  FastCell c;
-  c.valid = false;
-  c.cell  = -1;
-  if (slot >= nslots) return c;
-  const int4 d0 = b.cellDesc[3 * slot], d1 = b.cellDesc[3 * slot + 1], d2 = b.cellDesc[3 * slot + 2];
-  c.cell = d0.x;
-  if (c.cell < 0) return c;
-  c.level = d0.y;
-  c.tw = d0.w & 0xff, c.th = (d0.w >> 8) & 0xff;
-  c.iw = c.tw - 6, c.ih = c.th - 6;
-  c.ci_i = c.ci_j = 0;
-  *xoff = d1.x & 0xffff, *yoff = (d1.x >> 16) & 0xffff, *slotOff = d1.y;
-  if (!((d0.w >> 16) & 1)) return c;  // cell skipped by the reference (:782-793) or without interior: count stays 0
-  const int iniX = d0.z & 0xffff, iniY = (d0.z >> 16) & 0xffff;
-  c.ox = AL4 ? (iniX & 3) : 0;
-  if (c.level == 0) {
-    c.pitch = b.img0Pitch;
-    c.img   = b.img0 + (long long)f * b.img0FrameStride + (long long)iniY * c.pitch + iniX - c.ox;
-  } else {
-    c.pitch = d1.w;
-    c.img   = b.pyr + (long long)f * g.pyrBytes + d1.z - c.ox;
-  }
-  c.tw4 = (c.ox + c.tw + 3) >> 2;
-  c.n4  = c.tw4 * c.th;
-  c.mT4 = (unsigned)(AL4 ? d2.x : d2.y);  // 0xffffffff / tw4 + 1, from the host
-  c.mIw = (unsigned)d2.z;
-  c.valid = true;
-  return c;
-}
-
-// Issue the global loads of a cell's tile.  AL4 (level base and pitch 4-byte aligned -- always true for pyramid
-// levels >= 1, and for level 0 when the caller's image is): one aligned 32-bit load per slot, starting at the aligned
-// column below iniX; the up-to-3 extra bytes on either side lie inside the image row (cells end >= 16 px before the
-// row end).  Otherwise byte loads.
-// Staging map of a tile: thread = (dword column xw, row y0), rows y0, y0 + RPS, ...: no index arithmetic beyond one add per row.
-// XW lanes span a tile row (16 for the 52-byte stride, 32 for the 80-byte one); NPRE = row steps.
-template <int TS>
-struct FastStage {
-  static constexpr int XW  = TS <= 52 ? 16 : 32;
-  static constexpr int RPS = kFastThreads / XW;  // rows per step
-};
-
-template <bool AL4, int NPRE, int TS>
-__device__ __forceinline__ void fast_prefetch(const FastCell& c, int tid, uint32_t (&r)[NPRE]) {
-  if (!c.valid) return;
-  const int xw = tid & (FastStage<TS>::XW - 1), y0 = tid / FastStage<TS>::XW;
-  if (xw >= c.tw4) return;
-  const uint8_t* src = c.img + (long long)y0 * c.pitch + xw * 4;
-#pragma unroll
-  for (int k = 0; k < NPRE; k++) {
-    if (y0 + k * FastStage<TS>::RPS < c.th) {
-      const uint8_t* p = src + (long long)(k * FastStage<TS>::RPS) * c.pitch;
-      if (AL4) {
-        r[k] = *reinterpret_cast<const uint32_t*>(p);
-      } else {
-        const int x = xw * 4;
-        uint32_t  v = p[0];
-        if (x + 1 < c.tw) v |= (uint32_t)p[1] << 8;
-        if (x + 2 < c.tw) v |= (uint32_t)p[2] << 16;
-        if (x + 3 < c.tw) v |= (uint32_t)p[3] << 24;
-        r[k] = v;
-      }
-    }
-  }
-}
-
-// NPRE = tile dwords per thread for THIS image geometry (ceil(max tile dwords / 256); 3 at VGA, 7 worst case).
-// TS = LDS row stride of the tile (compile-time so that the 16 circle taps are immediate offsets): 52 covers every level
-// with at least four cell columns (cells <= 43 px wide), 80 the largest possible cell.  The LDS block is sized by the host
-// for the actual geometry (FastLds); at VGA it is ~10 KB, which together with the 64-register budget of the TS = 52
-// instantiation keeps 8 waves per SIMD resident -- the kernel spends half of its time behind barriers and LDS latency,
-// and residency is what hides that.
-struct FastLds {
-  int tileBytes;  // TS * (max tile height), multiple of 16
-  int maxInt;     // interior pixels of the largest cell (candList capacity), even
-  int kpCap;      // NMS survivors: at most one per 2x2 block, + 64
-};
-
-template <bool AL4, int NPRE, int TS>
-__global__ __launch_bounds__(kFastThreads, TS <= 52 ? 8 : 5) void k_fast_cells(Bufs b, FrameGeom g, int iniTh, int minTh, int nslots, int dbgSkip, FastLds fl) {
-  extern __shared__ __align__(16) uint8_t fastLds[];
-  uint8_t*        tile     = fastLds;                  // pixels, row stride TS
-  uint8_t*        score    = fastLds + fl.tileBytes;   // corner score (0 = not a corner at lowTh)
-  unsigned short* candList = reinterpret_cast<unsigned short*>(fastLds + 2 * fl.tileBytes);  // pass-1 survivors (pixel index in the interior)
-  // NMS survivors under either threshold.  No two of them are 8-neighbours (a survivor at minTh beats every neighbour; one
-  // at iniTh beats every neighbour that reaches iniTh, and a neighbouring minTh survivor would), hence the capacity.
-  unsigned short* kpList = candList + fl.maxInt;
-  __shared__ int  candCount, kpCount, cnt1, cnt2;
-  constexpr int   ts = TS;
-  const uint8_t*  tl = tile;
-  // Workgroup b walks kFastCellsPerBlock consecutive slots of XCD (b % 8)'s list in the host-built order table
-  // (whole cell ROWS dealt to the 8 XCDs, balanced by cell count: horizontally adjacent cells share 128-B lines and
-  // the 6-px overlap, so they sit behind one L2).  While a cell is processed the NEXT cell's tile is already in
-  // flight into registers, which hides the global-load latency that otherwise parks every wave at cell start.
-  const int f = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
-  const int xcd = blockIdx.x & 7, k0 = (blockIdx.x >> 3) * kFastCellsPerBlock;
-  const int lowTh = max(min(iniTh, minTh), 1);
-  uint32_t  pre[NPRE];
-  int       xoff = 0, yoff = 0, slotOff = 0, nxoff = 0, nyoff = 0, nslotOff = 0;
-  FastCell  cur = fast_decode<AL4>(b, g, k0 * 8 + xcd, nslots, f, &xoff, &yoff, &slotOff);
-  fast_prefetch<AL4, NPRE, TS>(cur, tid, pre);
-  for (int cc = 0; cc < kFastCellsPerBlock; cc++) {
-    FastCell nxt;
-    nxt.valid = false, nxt.cell = -1;
-    if (cc + 1 < kFastCellsPerBlock) nxt = fast_decode<AL4>(b, g, (k0 + cc + 1) * 8 + xcd, nslots, f, &nxoff, &nyoff, &nslotOff);
-    if (!cur.valid) {
-      if (cur.cell >= 0 && tid == 0) b.cellCount[(long long)f * g.totalCells + cur.cell] = 0;
-      cur = nxt, xoff = nxoff, yoff = nyoff, slotOff = nslotOff;
-      fast_prefetch<AL4, NPRE, TS>(cur, tid, pre);
-      continue;
-    }
-    const int iw = cur.iw, ih = cur.ih;
-    const unsigned   mIw = cur.mIw;  // interior-width divider for idx -> (row, col)
-    const int        ox3 = 3 + cur.ox;  // LDS column of interior column 0
-    // registers -> LDS (TS is a multiple of 4: aligned; spill past tw stays inside the row), same (column, row) map as the loads
-    {
-      const int xw = tid & (FastStage<TS>::XW - 1), y0 = tid / FastStage<TS>::XW;
-      if (xw < cur.tw4) {
-#pragma unroll
-        for (int k = 0; k < NPRE; k++) {
-          const int y = y0 + k * FastStage<TS>::RPS;
-          if (y < cur.th) {
-            *reinterpret_cast<uint32_t*>(tile + y * ts + xw * 4)  = pre[k];
-            *reinterpret_cast<uint32_t*>(score + y * ts + xw * 4) = 0;
-          }
-        }
-      }
-    }
-    if (tid == 0) candCount = 0, kpCount = 0, cnt1 = 0, cnt2 = 0;
-    __syncthreads();
-    fast_prefetch<AL4, NPRE, TS>(nxt, tid, pre);  // in flight during the four passes below
-    const int npix = iw * ih;
-    // Pass 1 -- necessary condition + compaction.  A 9-arc of the 16-pixel circle leaves out 7 contiguous positions, so
-    // it contains at least one of every two OPPOSITE positions: a pixel can only score >= lowTh if, for each of the four
-    // opposite pairs of even positions, one of the two is darker than v - lowTh (or, for the other polarity, one of the
-    // two is brighter than v + lowTh).  On the benchmark stream this keeps 5.6 % of the pixels -- the same as demanding four
-    // consecutive even positions -- at a third of the arithmetic.  Survivors go (any order) to an LDS list so that the
-    // full score below runs with all lanes busy.
-    // Two pixels per lane (A = pair index j, B = j + npairs) with packed 16-bit min/max: "every pair has one below lo"
-    // <=> max over the pairs of min(pair) < lo, and symmetrically for hi.
-    const int  npairs = (npix + 1) >> 1;
-    const pk16 tpk    = pk_pair(lowTh, lowTh);
-    for (int j = tid; j < ((npairs + 63) & ~63); j += kFastThreads) {
-      bool keepA = false, keepB = false;
-      int  idxA = 0, idxB = 0;
-      if (j < npairs && !(dbgSkip & 1)) {
-        idxA = j;
-        idxB = min(j + npairs, npix - 1);
-        const int      qa = div_magic(idxA, mIw), qb = div_magic(idxB, mIw);
-        const uint8_t* cA = tl + (3 + qa) * ts + ox3 + idxA - qa * iw;
-        const uint8_t* cB = tl + (3 + qb) * ts + ox3 + idxB - qb * iw;
-        const pk16     v  = pk_pair(cA[0], cB[0]);
-        const pk16     lo = v - tpk, hi = v + tpk;
-        pk16           p[8];
-        p[0] = pk_pair(cA[3 * ts], cB[3 * ts]);
-        p[1] = pk_pair(cA[2 * ts + 2], cB[2 * ts + 2]);
-        p[2] = pk_pair(cA[3], cB[3]);
-        p[3] = pk_pair(cA[-2 * ts + 2], cB[-2 * ts + 2]);
-        p[4] = pk_pair(cA[-3 * ts], cB[-3 * ts]);
-        p[5] = pk_pair(cA[-2 * ts - 2], cB[-2 * ts - 2]);
-        p[6] = pk_pair(cA[-3], cB[-3]);
-        p[7] = pk_pair(cA[2 * ts - 2], cB[2 * ts - 2]);
-        // opposite even positions: p[i] and p[i + 4]
-        pk16 dmin = pk_min(p[0], p[4]), bmax = pk_max(p[0], p[4]);
-#pragma unroll
-        for (int i = 1; i < 4; i++) {
-          dmin = pk_max(dmin, pk_min(p[i], p[i + 4]));  // largest  "darker one of an opposite pair"
-          bmax = pk_min(bmax, pk_max(p[i], p[i + 4]));  // smallest "brighter one of an opposite pair"
-        }
-        const uint32_t neg = pk_bits(dmin - lo) | pk_bits(hi - bmax);  // a negative half = that pixel passes
-        keepA              = (neg & 0x8000u) != 0;
-        keepB              = (neg & 0x80000000u) != 0 && (j + npairs < npix);
-      }
-      const unsigned long long balA = __ballot(keepA), balB = __ballot(keepB);
-      int                      base = 0;
-      if (lane == 0 && (balA | balB)) base = atomicAdd(&candCount, __popcll(balA) + __popcll(balB));
-      base = __shfl(base, 0, 64);
-      const unsigned long long below = (1ull << lane) - 1ull;
-      if (keepA) candList[base + __popcll(balA & below)] = (unsigned short)idxA;
-      if (keepB) candList[base + __popcll(balA) + __popcll(balB & below)] = (unsigned short)idxB;
-    }
-    lds_barrier();
-    // Pass 2 -- full corner score of the survivors
-    const int ncand = candCount;
-    for (int k = tid; k < ((dbgSkip & 2) ? 0 : ncand); k += kFastThreads) {
-      const int idx = candList[k];
-      const int q = div_magic(idx, mIw), y = 3 + q, x = ox3 + idx - q * iw;
-      const int sc = fast_score_pm(tl + y * ts + x, ts);
-      score[y * ts + x] = (uint8_t)(sc >= lowTh ? sc : 0);  // scores below both thresholds are never corners
-    }
-    lds_barrier();
-    // Pass 3 -- strict 3x3 NMS under both thresholds, over the survivors only.  Flags go to a sparse list.
-    for (int k = tid; k < ((ncand + 63) & ~63); k += kFastThreads) {
-      bool f1 = false, f2 = false;
-      int  idx = 0;
-      if (k < ncand) {
-        idx = candList[k];
-        const int q = div_magic(idx, mIw), y = 3 + q, x = ox3 + idx - q * iw;
-        const int s = score[y * ts + x];
-        if (s > 0) {
-          int m1 = 0, m2 = 0;  // max neighbour score under each threshold
-#pragma unroll
-          for (int dy = -1; dy <= 1; dy++)
-#pragma unroll
-            for (int dx = -1; dx <= 1; dx++)
-              if (dx | dy) {
-                const int t = score[(y + dy) * ts + x + dx];
-                m2          = max(m2, t >= minTh ? t : 0);  // (minThFAST may exceed iniThFAST: the reference does not check)
-                m1          = max(m1, t >= iniTh ? t : 0);
-              }
-          f1 = (s >= iniTh && s > m1);
-          f2 = (s >= minTh && s > m2);
-        }
-      }
-      const unsigned long long bal = __ballot(f1 || f2), b1 = __ballot(f1), b2 = __ballot(f2);
-      int                      base = 0;
-      if (lane == 0 && bal) {
-        base = atomicAdd(&kpCount, __popcll(bal));
-        if (b1) atomicAdd(&cnt1, __popcll(b1));
-        if (b2) atomicAdd(&cnt2, __popcll(b2));
-      }
-      base = __shfl(base, 0, 64);
-      if (f1 || f2) kpList[base + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)(idx | (f1 ? 0x8000 : 0) | (f2 ? 0x4000 : 0));
-    }
-    lds_barrier();
-    // vKeysCell.empty() at iniThFAST -> retry with minThFAST (:810-839)
-    const int      nk   = kpCount;
-    const unsigned selB = cnt1 > 0 ? 0x8000u : 0x4000u;
-    // Pass 4 -- row-major emission order (cv::FAST's): rank of every selected keypoint = number of selected keypoints
-    // with a smaller pixel index.  The list is short (a few to a few dozen entries per cell).
-    uint32_t* out = b.slots + (long long)f * g.totalSlots + slotOff;
-    if (tid == 0) b.cellCount[(long long)f * g.totalCells + cur.cell] = cnt1 > 0 ? cnt1 : cnt2;
-    for (int e = tid; e < nk; e += kFastThreads) {
-      const unsigned me = kpList[e];
-      if (me & selB) {
-        const int idx = me & 0x3fff;
-        int       rank = 0;
-        for (int o = 0; o < nk; o++) {
-          const unsigned ot = kpList[o];
-          rank += ((ot & selB) && (int)(ot & 0x3fff) < idx) ? 1 : 0;
-        }
-        const int q = div_magic(idx, mIw), y = 3 + q, x = ox3 + idx - q * iw;
-        out[rank]   = (uint32_t)(x - cur.ox + xoff) | ((uint32_t)(y + yoff) << 12) | ((uint32_t)score[y * ts + x] << 24);
-      }
-    }
-    lds_barrier();  // tile / score / lists are rewritten by the next cell
-    cur = nxt, xoff = nxoff, yoff = nyoff, slotOff = nslotOff;
-  }
 }
 
 }  // namespace orbx

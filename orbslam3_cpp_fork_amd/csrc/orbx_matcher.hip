@@ -46,6 +46,9 @@ constexpr int      kGridCols = 64, kGridRows = 48;  // FRAME_GRID_COLS / ROWS (i
   } while (0)
 
 thread_local std::string g_merr;
+extern "C" int           orbx_internal_runtime_down(void);
+extern "C" void          orbx_internal_register(void* obj, void (*release_device)(void*));
+extern "C" void          orbx_internal_unregister(void* obj);
 extern "C" void          orbx_internal_set_error(const char* s);  // orbx_extractor.hip: the slot orbx_last_error() reads
 void                     set_err(const std::string& s) {
   g_merr = s;
@@ -1347,6 +1350,8 @@ extern "C" {
 
 const char* orbm_last_error(void) { return g_merr.c_str(); }
 
+static void orbm_release_device_side(orbm_matcher* h);
+
 int orbm_create(orbm_t** out, int device_id) {
   if (!out) return -2;
   *out = nullptr;
@@ -1359,12 +1364,12 @@ int orbm_create(orbm_t** out, int device_id) {
     delete h;
     return -3;
   }
+  orbx_internal_register(h, [](void* p) { orbm_release_device_side(static_cast<orbm_matcher*>(p)); });
   *out = h;
   return 0;
 }
 
-void orbm_destroy(orbm_t* h) {
-  if (!h) return;
+static void orbm_release_device_side(orbm_matcher* h) {
   hipSetDevice(h->device);
   if (h->stream) {
     hipStreamSynchronize(h->stream);
@@ -1375,6 +1380,13 @@ void orbm_destroy(orbm_t* h) {
   h->nm.release(), h->gidx.release(), h->qa.release(), h->ta.release(), h->prev.release(), h->topk.release(), h->kp1.release();
   h->kp2.release(), h->dbg.release();
   h->in.release(), h->out.release();
+  h->stream = nullptr;
+}
+
+void orbm_destroy(orbm_t* h) {
+  if (!h) return;
+  orbx_internal_unregister(h);
+  if (!orbx_internal_runtime_down()) orbm_release_device_side(h);  // else: process teardown, the exit handler (orbx_extractor.hip) has released it
   delete h;
 }
 

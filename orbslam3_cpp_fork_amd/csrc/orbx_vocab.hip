@@ -30,6 +30,9 @@
 namespace {
 
 thread_local std::string g_verr;
+extern "C" int           orbx_internal_runtime_down(void);
+extern "C" void          orbx_internal_register(void* obj, void (*release_device)(void*));
+extern "C" void          orbx_internal_unregister(void* obj);
 extern "C" void          orbx_internal_set_error(const char* s);  // orbx_extractor.hip: the slot orbx_last_error() reads
 void                     set_verr(const std::string& s) {
   g_verr = s;
@@ -407,6 +410,7 @@ static int vocab_from_arrays(orbv_vocab* h, int k, int L, int n, const int* pare
   return 0;
 }
 
+static void orbv_release_device_side(orbv_vocab* h);
 static int vocab_new(orbv_vocab** out, int device_id) {
   *out = nullptr;
   HIP_TRYV(hipSetDevice(device_id));
@@ -418,6 +422,7 @@ static int vocab_new(orbv_vocab** out, int device_id) {
     delete h;
     return -3;
   }
+  orbx_internal_register(h, [](void* p) { orbv_release_device_side(static_cast<orbv_vocab*>(p)); });
   *out = h;
   return 0;
 }
@@ -426,8 +431,7 @@ extern "C" {
 
 const char* orbv_last_error(void) { return g_verr.c_str(); }
 
-void orbv_destroy(orbv_t* h) {
-  if (!h) return;
+static void orbv_release_device_side(orbv_vocab* h) {
   hipSetDevice(h->device);
   if (h->stream) {
     hipStreamSynchronize(h->stream);
@@ -436,6 +440,13 @@ void orbv_destroy(orbv_t* h) {
   h->dDesc.release(), h->dChildOff.release(), h->dChildIds.release(), h->dChildCnt.release(), h->dWordId.release(), h->dWeight.release();
   h->wFeatWord.release(), h->wFeatNode.release(), h->wBowWords.release(), h->wFvNodes.release(), h->wFvFeat.release(), h->wFeatW.release();
   h->wBowVals.release(), h->wParkVal.release(), h->wParkOff.release(), h->wHead.release(), h->wDesc.release(), h->wFvOff.release(), h->wNW.release(), h->wNN.release();
+  h->stream = nullptr;
+}
+
+void orbv_destroy(orbv_t* h) {
+  if (!h) return;
+  orbx_internal_unregister(h);
+  if (!orbx_internal_runtime_down()) orbv_release_device_side(h);  // else: process teardown, the exit handler (orbx_extractor.hip) has released it
   delete h;
 }
 

@@ -26,6 +26,9 @@ class ORBextractor:
             self._h = None
 
     def __del__(self):
+        # Also during interpreter shutdown: the destroy entry points are safe at any point of process teardown (the library releases the
+        # device side of live handles from its own exit handler and only frees host state afterwards), and a handle that is destroyed is
+        # one the runtime does not find alive in its own teardown.
         try:
             self.close()
         except Exception:
@@ -67,6 +70,10 @@ class ORBextractor:
     def set_graph_replay(self, enable):
         """orbx_set_graph_replay: record the single-image call once (second call of a shape) and replay it as a hipGraph."""
         check(_lib.lib().orbx_set_graph_replay(self._h, int(bool(enable))), "orbx_set_graph_replay")
+
+    def set_pyramid_download(self, enable):
+        """orbx_set_pyramid_download: levels >= 1 come home inside every single-frame call (what the C++ adaptor's mbDownloadPyramid turns on)."""
+        check(_lib.lib().orbx_set_pyramid_download(self._h, 1 if enable else 0), "orbx_set_pyramid_download")
 
     def set_tap_contraction(self, mode):
         """Tap-rotation evaluation of computeOrbDescriptor (include/orbx.h): 1 = reference as built on an FMA host (default), 0 = none, 2 = other."""

@@ -126,6 +126,9 @@ class CommGather:
             self._h = None
 
     def __del__(self):
+        # Also during interpreter shutdown: the destroy entry points are safe at any point of process teardown (the library releases the
+        # device side of live handles from its own exit handler and only frees host state afterwards), and a handle that is destroyed is
+        # one the runtime does not find alive in its own teardown.
         try:
             self.close()
         except Exception:

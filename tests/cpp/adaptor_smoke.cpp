@@ -25,7 +25,6 @@ int main(int argc, char** argv) {
   const int rows = atoi(argv[1]), cols = atoi(argv[2]);
   std::vector<unsigned char> A = slurp(argv[3], (size_t)rows * cols), B = slurp(argv[4], (size_t)rows * cols);
   ORB_SLAM3::ORBextractor*   ext = new ORB_SLAM3::ORBextractor(1000, 1.2f, 8, 20, 7);  // src/Tracking.cc:576
-  ext->mbDownloadPyramid = true;  // this test reads mvImagePyramid as the reference's host-side ComputeStereoMatches would
   std::vector<int>           vLapping = {0, 1000};                                      // mono convention, src/Frame.cc:451
   orbx_cv::Mat               imA(rows, cols, orbx_cv::CV_8U, A.data()), imB(rows, cols, orbx_cv::CV_8U, B.data()), dA, dB;
   std::vector<orbx_cv::KeyPoint> kA, kB;

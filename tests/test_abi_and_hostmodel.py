@@ -217,3 +217,48 @@ def test_bad_arguments_are_rejected_before_the_device():
         f.write("30 6 0 0\n")  # k > 20 (TemplatedVocabulary.h:1358-1362)
     assert L.orbv_load_text(C.byref(h), f.name.encode(), 0) == -2
     os.unlink(f.name)
+
+
+def test_rccl_that_cannot_be_opened_is_an_error_not_a_crash():
+    """orbx_comm_unique_id / orbx_comm_create on a host where no RCCL can be opened return -3 with the loader's message
+    (ORBX_RCCL_LIBRARY names the one library to try).  Own process: the library caches a successful open."""
+    import subprocess
+    import sys
+
+    code = (
+        "import ctypes as C, sys\n"
+        "from orbslam3_cpp_fork_amd import _lib\n"
+        "L = _lib.lib()\n"
+        "buf = (C.c_uint8 * 128)()\n"
+        "rc = L.orbx_comm_unique_id(buf)\n"
+        "msg = _lib.last_error()\n"
+        "h = C.c_void_p()\n"
+        "rc2 = L.orbx_comm_create(C.byref(h), 0, 0, 1, buf)\n"
+        "print(rc, rc2, msg)\n"
+        "sys.exit(0 if (rc == -3 and rc2 == -3 and 'cannot open' in msg and 'no_such_rccl' in msg) else 1)\n"
+    )
+    env = dict(os.environ, ORBX_RCCL_LIBRARY="/nonexistent/libno_such_rccl.so", PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, (r.stdout, r.stderr)
+
+
+def test_env_switches_of_the_product_library_are_few_and_tested():
+    """Every getenv("ORBX_...") the default build of liborbx.so reads is named in a test; tuning switches only exist under -DORBX_TUNING."""
+    csrc = os.path.join(ROOT, "orbslam3_cpp_fork_amd", "csrc")
+    live, tuning = set(), set()
+    for f in os.listdir(csrc):
+        if not f.endswith((".hip", ".h", ".cpp")):
+            continue
+        depth = 0
+        for line in open(os.path.join(csrc, f)):
+            t = line.strip()
+            if t.startswith("#ifdef ORBX_TUNING"):
+                depth += 1
+            elif t.startswith("#endif") and depth:
+                depth -= 1
+            for name in re.findall(r'getenv\("(ORBX_[A-Z0-9_]+)"\)', line):
+                (tuning if depth else live).add(name)
+    assert live == {"ORBX_FAST_CAND_CAP", "ORBX_NO_REPITCH", "ORBX_GRAPH", "ORBX_RCCL_LIBRARY"}, live
+    tests = "".join(open(os.path.join(ROOT, "tests", f)).read() for f in os.listdir(os.path.join(ROOT, "tests")) if f.endswith(".py"))
+    for name in live:
+        assert ('setenv("%s"' % name) in tests or ('%s=' % name) in tests, name

@@ -175,3 +175,73 @@ def test_reference_matcher_bodies_match_oracle(tmp_path, oracle):
                                                (0.0, 640.0, 0.0, 480.0), 100, True)
     assert npj == n3 and n3 > 100
     assert [int(x) for x in lines[p + 1 + nA: p + 1 + nA + nB]] == loc.tolist()
+
+
+# ---- an unchanged Frame::ComputeStereoMatches over the adaptor's public mvImagePyramid; handles destroyed after main() ----------------
+def _build_cpp(tmp, name):
+    from orbslam3_cpp_fork_amd import build
+
+    so = build.build()
+    exe = os.path.join(tmp, name)
+    subprocess.check_call(
+        ["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), "-DORBX_NO_OPENCV", os.path.join(ROOT, "tests", "cpp", name + ".cpp"),
+         "-o", exe, "-L" + os.path.dirname(so), "-lorbx", "-Wl,-rpath," + os.path.dirname(so)]
+    )
+    return exe
+
+
+def test_stereo_body_and_static_lifetime_compile(tmp_path):
+    assert os.path.exists(_build_cpp(str(tmp_path), "stereo_frame_body"))
+    assert os.path.exists(_build_cpp(str(tmp_path), "static_lifetime"))
+
+
+@pytest.mark.gpu
+def test_unchanged_stereo_body_reads_the_public_pyramid(tmp_path, oracle):
+    """A Frame::ComputeStereoMatches-shaped host body (reference src/Frame.cc:944-1113) that takes its SAD pixels from
+    mpORBextractor{Left,Right}->mvImagePyramid[kpL.octave] (:1039-1058) with the adaptor's DEFAULT settings, against orbx_stereo_matches on
+    the same pair and against the oracle: all three agree on the float bits of every mvuRight / mvDepth."""
+    from orbslam3_cpp_fork_amd import synth
+
+    exe = _build_cpp(str(tmp_path), "stereo_frame_body")
+    h, w = 376, 1240
+    left, right = synth.make_stereo_pair(h, w, camera_idx=11)
+    fl, fr, out = (str(tmp_path / n) for n in ("l.raw", "r.raw", "out.txt"))
+    left.tofile(fl)
+    right.tofile(fr)
+    subprocess.check_call([exe, str(h), str(w), fl, fr, out], timeout=300)
+    lines = open(out).read().split("\n")
+    ol, orr = oracle.OracleExtractor(1200, 1.2, 8, 20, 7), oracle.OracleExtractor(1200, 1.2, 8, 20, 7)
+    _, kl, dl = ol(left, (0, 0))
+    _, kr, dr = orr(right, (0, 0))
+    mbf = np.float32(386.1448)  # KITTI 00-02: bf, b = bf / fx (the program computes mb the same way)
+    mb = np.float32(mbf / np.float32(718.856))
+    n0, u0, d0 = oracle.stereo_matches(ol, orr, kl, dl, kr, dr, float(mb), float(mbf))
+    hdr = [int(x) for x in lines[0].split()]
+    assert hdr[:2] == [len(kl), len(kr)] and hdr[2] == hdr[3] == n0 and n0 > 30
+    assert hdr[4] == w and hdr[5] == 346  # mvImagePyramid[0] / [7] are filled without any opt-in (cvRound(1240 * 0.2790816) = 346)
+    got = np.array([[float.fromhex(x) for x in ln.split()] for ln in lines[1: 1 + len(kl)]], np.float32)
+    assert (got[:, 0].view(np.uint32) == u0.view(np.uint32)).all() and (got[:, 1].view(np.uint32) == d0.view(np.uint32)).all(), "host body over mvImagePyramid differs from the oracle"
+    assert (got[:, 2].view(np.uint32) == u0.view(np.uint32)).all() and (got[:, 3].view(np.uint32) == d0.view(np.uint32)).all(), "orbx_stereo_matches differs from the oracle"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["destroy", "leak"])
+def test_handles_destroyed_after_main_returns(tmp_path, mode):
+    """Adaptor objects with static storage duration, an atexit handler that destroys raw handles, and (mode 'leak') handles that are never
+    destroyed (the reference never deletes its extractors, src/Tracking.cc:576-585): the process exits 0 without a fault."""
+    exe = _build_cpp(str(tmp_path), "static_lifetime")
+    r = subprocess.run([exe] + (["leak"] if mode == "leak" else []), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    assert r.stdout.startswith("ok ")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["leak", "close", "late"])
+def test_python_process_exit_paths(mode):
+    """A Python host that never closes its extractor (leak), closes it, or lets it die while the interpreter finalizes: exit status 0.
+    (Handles leaked into the HIP runtime's own teardown ended the process with SIGSEGV under rocprofv3 before the library's exit handler
+    released them itself; tools/dbg_exit_modes.py is the probe, also run under the profiler by tools/collect_profiles.sh.)"""
+    import sys
+
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dbg_exit_modes.py"), mode], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "done" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-2000:])

@@ -303,3 +303,106 @@ def test_graph_replay_of_the_single_call(oracle):
     ref.set_graph_replay(False)
     a, b = ex(frames[0], None, (0, 1000)), ref(frames[0], None, (0, 1000))
     assert a[1].tobytes() == b[1].tobytes() and a[2].tobytes() == b[2].tobytes()
+
+
+@pytest.mark.gpu
+def test_replayed_call_owns_the_pyramid_accessors(oracle):
+    """A replayed orbx_extract must leave the handle's host-side state as an eager call does: after a batch call on the SAME handle and the
+    same workspace (no reallocation, so the recorded graph stays valid) level 0 of orbx_pyramid_level -- the adaptor's mvImagePyramid[0], and
+    the level-0 SAD source of orbx_stereo_matches -- is the replayed call's own image again, not the batch's caller-owned frames."""
+    import torch
+
+    from orbslam3_cpp_fork_amd import synth
+    from orbslam3_cpp_fork_amd.extractor import ORBextractor
+
+    rows, cols, B = 240, 320, 4
+    frames = synth.make_stream(rows, cols, 6, camera_idx=4)
+    ex = ORBextractor(500)
+    oex = oracle.OracleExtractor(500, 1.2, 8, 20, 7)
+    d = torch.from_numpy(synth.make_stream(rows, cols, B, camera_idx=9)).cuda()
+    cap = ex.max_keypoints(rows, cols)
+    kps = torch.zeros((B, cap, 7), device="cuda")
+    desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
+    cnt = torch.zeros((B, 2), dtype=torch.int32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    ex.extract_batch_device(d, B, rows, cols, cols, rows * cols, kps, desc, cnt, cap, (0, 0), stream=st)  # workspace for B frames exists from here on
+    torch.cuda.synchronize()
+    for download in (False, True):
+        ex.set_pyramid_download(download)
+        for i, fr in enumerate(frames):  # eager, record, replay, ... with a batch call between every two
+            rc, k, dd = ex(fr, None, (0, 0))
+            rc0, k0, d0 = oex(fr, (0, 0))
+            assert rc == rc0 and (k.view(np.uint32) == k0.view(np.uint32)).all() and (dd == d0).all()
+            assert (ex.pyramid_level(0) == fr).all(), ("level 0 after call %d is not the call's image" % i)
+            for l in (1, 4, 7):
+                assert (ex.pyramid_level(l) == oex.pyramid_level(l)).all(), (download, i, l)
+            ex.extract_batch_device(d, B, rows, cols, cols, rows * cols, kps, desc, cnt, cap, (0, 0), stream=st)
+            torch.cuda.synchronize()
+            assert (ex.pyramid_level(0, frame=2) == d[2].cpu().numpy()).all()  # and the batch call owns them after itself
+
+
+@pytest.mark.gpu
+def test_async_tickets_waited_in_any_order(oracle):
+    """include/orbx.h promises that tickets may be waited for in any order: waiting for the NEWEST first must free a slot for the next
+    submission (the old ring took slot ticket % depth and refused while a slot was free)."""
+    from orbslam3_cpp_fork_amd import synth
+    from orbslam3_cpp_fork_amd._lib import KP_DTYPE
+    from orbslam3_cpp_fork_amd.extractor import ORBextractor, pinned_array
+
+    h, w, nf, B, nchunks = 240, 320, 500, 2, 6
+    frames = synth.make_stream(h, w, B * nchunks, camera_idx=8)
+    ex = ORBextractor(nf)
+    oex = oracle.OracleExtractor(nf, 1.2, 8, 20, 7)
+    cap = ex.max_keypoints(h, w)
+    imgs = [pinned_array((B, h, w), np.uint8) for _ in range(nchunks)]
+    for c in range(nchunks):
+        imgs[c][:] = frames[c * B: (c + 1) * B]
+    outs = [(pinned_array((B, cap), KP_DTYPE), pinned_array((B, cap, 32), np.uint8), pinned_array((B, 2), np.int32)) for _ in range(nchunks)]
+    ex.set_async_depth(3)
+    t = [ex.extract_async(imgs[c], *outs[c], cap, (0, 0)) for c in range(3)]
+    ex.wait(t[2])                                              # newest first
+    t.append(ex.extract_async(imgs[3], *outs[3], cap, (0, 0)))  # must find the freed slot
+    ex.wait(t[1])
+    t.append(ex.extract_async(imgs[4], *outs[4], cap, (0, 0)))
+    ex.wait(t[4])
+    ex.wait(t[0])
+    t.append(ex.extract_async(imgs[5], *outs[5], cap, (0, 0)))
+    ex.wait(t[3])
+    ex.wait(t[5])
+    for c in range(nchunks):
+        k, d, cnt = outs[c]
+        for f in range(B):
+            rc0, k0, d0 = oex(frames[c * B + f], (0, 0))
+            n = int(cnt[f, 0])
+            assert n == len(k0) and (k[f, :n].view(np.uint32) == k0.view(np.uint32)).all() and (d[f, :n] == d0).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cap_entries", ["2", "64", "300"])
+def test_fast_candidate_list_overflow(oracle, vga_frame, cap_entries, monkeypatch):
+    """ORBX_FAST_CAND_CAP shrinks the per-tile candidate list of k_fast_tiles: lanes whose pre-test survivors do not fit keep them and score
+    them themselves.  Results must not depend on the list size (the default 2048 never overflows on natural images, so this path would
+    otherwise only be reached by adversarial inputs)."""
+    from orbslam3_cpp_fork_amd.extractor import ORBextractor
+
+    monkeypatch.setenv("ORBX_FAST_CAND_CAP", cap_entries)
+    ex = ORBextractor(1000)
+    oex = oracle.OracleExtractor(1000, 1.2, 8, 20, 7)
+    noise = np.random.default_rng(5).integers(0, 256, vga_frame.shape, dtype=np.uint8)  # every other pixel survives the pre-test
+    for img in (vga_frame, noise):
+        rc, k, d = ex(img, None, (0, 0))
+        rc0, k0, d0 = oex(img, (0, 0))
+        assert rc == rc0 and len(k) == len(k0) and (k.view(np.uint32) == k0.view(np.uint32)).all() and (d == d0).all()
+
+
+@pytest.mark.gpu
+def test_graph_env_switch(oracle, vga_frame, monkeypatch):
+    """ORBX_GRAPH=0 keeps every orbx_extract eager (the operator's switch beside orbx_set_graph_replay); results are the same."""
+    from orbslam3_cpp_fork_amd.extractor import ORBextractor
+
+    monkeypatch.setenv("ORBX_GRAPH", "0")
+    ex = ORBextractor(1000)
+    rc0, k0, d0 = oracle.OracleExtractor(1000, 1.2, 8, 20, 7)(vga_frame, (0, 1000))
+    for _ in range(4):
+        rc, k, d = ex(vga_frame, None, (0, 1000))
+        assert rc == rc0 and (k.view(np.uint32) == k0.view(np.uint32)).all() and (d == d0).all()
