@@ -433,7 +433,10 @@ int orbx_extractor::makeGeometry(int rows, int cols) {
   // ---- k_fast_tiles: tiles = runs of horizontally adjacent valid cells of one cell row (orbx_fast_tiles.h)
   {
     auto magic = [](unsigned d) { return d <= 1 ? 0u : 0xffffffffu / d + 1u; };
-    const int              kTileBudget = 8192;  // LDS bytes of one pixel tile
+    int                    kTileBudget = 8192;  // LDS bytes of one pixel tile
+#ifdef ORBX_TUNING
+    if (getenv("ORBX_FAST_TILE_BYTES")) kTileBudget = atoi(getenv("ORBX_FAST_TILE_BYTES"));
+#endif
     std::vector<FastTile>  tiles;
     struct RowRef {
       int first, count, px;
@@ -534,12 +537,14 @@ int orbx_extractor::makeGeometry(int rows, int cols) {
     // LDS plan
     const int region = alignUp(maxTileBytes + 32, 16);
     FastLds2  fl{};
-    fl.scoreOff = alignUp(16 + region, 16);
-    fl.scoreBytes = region;
-    fl.candOff  = fl.scoreOff + region;
+    // {tile, 7-bit copy} + candidate list + corner list + masks + counters; the score map reuses the copy after the pre-test (orbx_fast_tiles.h)
+    fl.t7Off    = alignUp(16 + region, 16) + 16;  // the copy is addressed like the tile: reads reach 4 bytes before its origin
+    fl.scoreOff = fl.t7Off, fl.scoreBytes = region;
+    fl.candOff  = fl.t7Off + region;
     // candidate list entries; lanes whose survivors do not fit score them themselves (ORBX_FAST_CAND_CAP: tests shrink the list to reach that path)
     fl.candCap  = getenv("ORBX_FAST_CAND_CAP") ? std::max(atoi(getenv("ORBX_FAST_CAND_CAP")), 2) : 2048;
-    fl.mask1Off = alignUp(fl.candOff + 2 * fl.candCap, 16);
+    fl.listCOff = alignUp(fl.candOff + 2 * fl.candCap, 16);
+    fl.mask1Off = alignUp(fl.listCOff + 2 * fl.candCap, 16);
     fl.mask2Off = fl.mask1Off + 4 * maxCells * maxW;
     fl.cntOff   = fl.mask2Off + 4 * maxCells * maxW;
     fl.total    = alignUp(fl.cntOff + 4 * (maxCells + 3), 16);
