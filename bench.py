@@ -285,11 +285,14 @@ def profile_summaries():
     """Committed profile summaries of THIS command (tools/collect_profiles.sh): bench.py cannot read hardware counters itself, so the
     HBM traffic and the VALU utilisation in the JSON line are those of the profiled run, tagged with their source file."""
     out = {}
-    for key, name in (("pmc", "r02_pmc_summary.json"), ("valu", "r02_valu_summary.json")):
-        try:
-            out[key] = (name, json.load(open(os.path.join(ROOT, "profiles", name))))
-        except Exception:
-            out[key] = None
+    for key, names in (("pmc", ("r03_pmc_summary.json", "r02_pmc_summary.json")), ("valu", ("r03_valu_summary.json", "r02_valu_summary.json"))):
+        out[key] = None
+        for name in names:  # the newest round's summary that is committed
+            try:
+                out[key] = (name, json.load(open(os.path.join(ROOT, "profiles", name))))
+                break
+            except Exception:
+                pass
     return out
 
 
@@ -414,6 +417,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive pass (host frames in, host records out)")
     ap.add_argument("--no-match", action="store_true", help="extract only")
+    ap.add_argument("--no-single-call", action="store_true", help="skip the single synchronous orbx_extract latency figures (single_call_ms)")
     ap.add_argument("--c-gather", action="store_true", help="multi-rank runs: gather the records with orbx_gather (RCCL behind the C ABI) instead of torch.distributed.gather")
     ap.add_argument("--lanes", type=int, default=3, help="chunks in flight, each with its own handles, buffers and a HIP stream that owns a hardware queue: "
                     "the latency-bound kernels of one chunk (quadtree, claim resolution) run beside the VALU-bound ones of the others; 1 = strictly serial")
@@ -467,6 +471,11 @@ def main():
         total_frames_per_step = B * world
     d_imgs = torch.from_numpy(frames_np).to(dev)
     d_pairs = torch.from_numpy(pairs).to(dev)
+    # Four DISTINCT resident chunks rotate through the lanes (the stream, and the stream mirrored vertically / horizontally / both: other
+    # bytes, same statistics, consecutive frames still match): 4 x 78.6 MB of level-0 input at VGA is more than the 256 MiB Infinity
+    # Cache, so no step finds the frames it reads left behind by the step before.
+    d_chunks = [d_imgs, d_imgs.flip(1).contiguous(), d_imgs.flip(2).contiguous(), d_imgs.flip(1, 2).contiguous()]
+    NCH = len(d_chunks)
 
     voc = None
     if args.bow and not args.no_match:
@@ -515,9 +524,9 @@ def main():
                             "fv_nodes": z((B, self.cap), torch.int32), "fv_off": z((B, self.cap + 1), torch.int32), "fv_feat": z((B, self.cap), torch.int32),
                             "n_nodes": z(B, torch.int32)}
 
-        def step(self, timed=False):
+        def step(self, timed=False, chunk=0):
             with torch.cuda.stream(self.tstream):
-                self.ex.extract_batch_device(d_imgs, B, rows, cols, cols, rows * cols, self.d_kps, self.d_desc, self.d_cnt, self.cap, (0, 1000), stream=self.stream)
+                self.ex.extract_batch_device(d_chunks[chunk % NCH], B, rows, cols, cols, rows * cols, self.d_kps, self.d_desc, self.d_cnt, self.cap, (0, 1000), stream=self.stream)
                 if not args.no_match:
                     if voc is not None:
                         if timed:
@@ -574,21 +583,21 @@ def main():
 
     nwarm = max(args.warmup, len(lanes))  # every lane allocates its workspace and uploads its tables in its first step: never inside the timed region
     for i in range(nwarm):
-        lanes[i % len(lanes)].step()
+        lanes[i % len(lanes)].step(chunk=i)
     fence(c, lanes)
     stage_events = os.environ.get("ORBX_BENCH_NO_STAGE_EVENTS") is None  # A/B switch: what the HIP events between the stages cost the timed region
     for ln in lanes:
         ln.ex.set_profiling(stage_events)
     t0 = time.perf_counter()
     for i in range(args.steps):
-        lanes[i % len(lanes)].step(timed=stage_events)
+        lanes[i % len(lanes)].step(timed=stage_events, chunk=nwarm + i)
     fence(c, lanes)
     dt = max_over_ranks(c, time.perf_counter() - t0)
     if not stage_events:  # the stage figures then come from four more steps after the clock has stopped
         for ln in lanes:
             ln.ex.set_profiling(True)
         for i in range(4 * len(lanes)):
-            lanes[i % len(lanes)].step(timed=True)
+            lanes[i % len(lanes)].step(timed=True, chunk=i)
         fence(c, lanes)
     stages = []
     for ln in lanes:
@@ -610,8 +619,8 @@ def main():
         ln = lanes[0]
         ln.ex.set_profiling(True)
         ln.match_ev = []
-        for _ in range(4):
-            ln.step(timed=True)
+        for i in range(4):
+            ln.step(timed=True, chunk=i)
             fence(c, lanes)
         stage_serial = ln.ex.stage_ms()
         stage_serial["match"] = float(np.mean([a.elapsed_time(b) for a, b in ln.match_ev])) if ln.match_ev else 0.0
@@ -619,6 +628,23 @@ def main():
     cnt = lanes[0].d_cnt.cpu().numpy()
     nm = lanes[0].d_nm.cpu().numpy()
     value = total_frames_per_step * args.steps / dt
+    # the exchange step on its own (BASELINE.md config 5 asks for the gather latency): five gathers of lane 0's records, one at a time,
+    # barrier before and a device synchronisation after each; maximum over the ranks of the median
+    gather_ms = None
+    if world > 1:
+        ln, ts = lanes[0], []
+        for _ in range(5):
+            fence(c, lanes)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            with torch.cuda.stream(ln.tstream):
+                if ln.cgather is not None:
+                    ln.cgather(ln.d_kps, ln.d_desc, ln.d_cnt, stream=ln.stream)
+                else:
+                    ln.gather(ln.d_kps, ln.d_desc, ln.d_cnt, async_op=False)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t1)
+        gather_ms = max_over_ranks(c, float(np.median(ts))) * 1e3
 
     # ---- PCIe-inclusive pass: the same steps fed from pinned host memory through the streaming ABI ------------------------------
     pcie = None
@@ -627,11 +653,13 @@ def main():
             ln.close()
         from orbslam3_cpp_fork_amd._lib import KP_DTYPE
 
-        # two distinct chunks alternate (the second one = the first flipped upside down: other bytes, same statistics), so no step
-        # re-reads the chunk the previous step left in the caches
-        h_imgs = [pinned_array((B, rows, cols), np.uint8) for _ in range(2)]
+        # four distinct chunks rotate (the stream and its three mirror images: other bytes, same statistics), so no step re-reads a
+        # chunk an earlier step left in the caches
+        h_imgs = [pinned_array((B, rows, cols), np.uint8) for _ in range(4)]
         h_imgs[0][:] = frames_np
         h_imgs[1][:] = frames_np[:, ::-1, :]
+        h_imgs[2][:] = frames_np[:, :, ::-1]
+        h_imgs[3][:] = frames_np[:, ::-1, ::-1]
         NH, depth = int(os.environ.get("ORBX_BENCH_HOST_HANDLES", "1")), int(os.environ.get("ORBX_BENCH_HOST_DEPTH", "3"))  # one handle, three chunks in flight: the path is bound by the H2D copies (two or three handles side by side, ORBX_BENCH_HOST_HANDLES, measured 157-161 k against 167 k frames/s)
 
         class HostLane:
@@ -670,7 +698,7 @@ def main():
         hl = [HostLane() for _ in range(NH)]
 
         def host_step(i):
-            hl[i % NH].submit(h_imgs[i % 2])
+            hl[i % NH].submit(h_imgs[i % len(h_imgs)])
 
         def host_drain():
             for x in hl:
@@ -695,7 +723,7 @@ def main():
             # what one large pinned host -> device copy reaches on this pool with nothing else running (tools/dbg_pcie.py: 57 GB/s)
             "h2d_measured_limit_frames_per_s_per_gpu": round(PCIE_MEASURED_H2D_GBS * 1e9 / (rows * cols), 1),
             "what": "same steps from pinned host memory via orbx_extract_async / orbx_wait (3 chunks in flight): timed region = H2D of every frame + "
-                    "kernels + D2H of every fixed-capacity keypoint / descriptor / count record and of the match lists; two distinct chunks alternate",
+                    "kernels + D2H of every fixed-capacity keypoint / descriptor / count record and of the match lists; four distinct chunks rotate",
             "keypoints_per_frame": float(hl[0].h_cnt[hl[0].last][:, 0].mean()),
             "matches_per_frame": None if args.no_match else float(hl[0].h_nm[hl[0].last].mean()),
         }
@@ -703,6 +731,22 @@ def main():
             x.ex.close()
             x.mt.close()
         del h_imgs, hl
+
+    # ---- the call Frame::ExtractORB really makes (reference src/Frame.cc:555-562): ONE synchronous orbx_extract per frame, host image in,
+    # host records out (single-frame latency).  Median wall time of 40 calls after 8, per size.
+    single_call = None
+    if rank == 0 and world == 1 and not args.no_single_call:
+        single_call = {}
+        for (h1, w1, nf1) in ((480, 640, 1000), (480, 752, 1000), (376, 1241, 2000)):
+            img = synth.make_frame(h1, w1, 2, 3)
+            ex1 = ORBextractor(nf1, 1.2, 8, 20, 7, device=local_rank)
+            ts = []
+            for i in range(48):
+                t1 = time.perf_counter()
+                ex1(img, None, (0, 1000))
+                ts.append(time.perf_counter() - t1)
+            single_call["%dx%d/%d" % (w1, h1, nf1)] = round(float(np.median(ts[8:])) * 1e3, 4)
+            ex1.close()
 
     if rank == 0:
         ab = algorithmic_bytes(rows, cols, nfeat)
@@ -734,13 +778,24 @@ def main():
             name, summ = prof["valu"]
             try:
                 k = summ["kernels"][first]
-                valu = {"bound": "valu", "kernel": first, "achieved": k["valu_ginst_per_s"], "peak": summ["calibration"]["peak_ginst_per_s"], "unit": "G wave-instr/s",
-                        "frac": k["valu_frac"], "source": "profiles/" + name}
+                valu = {"bound": "valu", "kernel": first, "achieved": k["valu_ginst_per_s"], "peak": k["kernel_ceiling_ginst_per_s"], "unit": "G wave-instr/s",
+                        "frac": k["valu_frac"], "valu_insts_per_launch": k["valu_insts_per_launch"],
+                        "peak_is": "this kernel's own issue ceiling 1 / (f_full / R_full + f_half / R_half) from its static rate-class mix (tools/valu_mix.py) and the "
+                                   "two measured issue rates (tools/valu_calibrate.py: %.0f / %.0f G wave-instr/s); frac = achieved / peak" % (
+                                       summ["calibration"].get("full_rate_ginst_per_s", summ["calibration"].get("vop2_ginst_per_s", 0)),
+                                       summ["calibration"].get("half_rate_ginst_per_s", summ["calibration"].get("vop3_ginst_per_s", 0))),
+                        "source": "profiles/" + name}
             except Exception:
                 valu = None
+        # config 3's matcher figure: descriptor pairs compared per second by the brute-force pass (nq x nt per frame pair), priced with the
+        # match stage's own duration (one chunk in flight when that was measured)
+        n_kp = cnt[:, 0].astype(np.float64)
+        pair_count = float((n_kp[pairs[:, 0]] * n_kp[pairs[:, 1]]).sum())
+        match_ms = (stage_serial or stage).get("match", 0.0)
         out = {
             "metric": "frames/s ORB extract+match (640x480, 8 lvl, 1000 feat)" if cols == 640 else "frames/s ORB extract+match",
             "value": round(value, 2),
+            "value_pcie_inclusive": None if pcie is None else pcie["value"],
             "unit": "frames/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -753,7 +808,12 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": args.workload + ("" if not args.no_match else " [extract only]") + (" [+ BoW transform, SearchByBoW over FeatureVector groups]" if voc is not None else ""),
+                "value_definition": "value: the chunks are resident in HBM when the timed region starts (the bench contract).  SURVEY.md 8(d)'s GPU-timing row "
+                                    "('include H2D of the image and D2H of results') is value_pcie_inclusive: the same steps from pinned host memory, every "
+                                    "frame uploaded and every record downloaded inside the timed region",
                 "frames_per_step_per_gpu": B,
+                "distinct_resident_chunks": NCH,
+                "resident_input_MB": round(NCH * B * rows * cols / 1e6, 1),
                 "chunks_in_flight": len(lanes),
                 "stage_ms_note": "stage_ms / roofline.timed_region: HIP events on each chunk's own stream inside the timed region, i.e. WITH the other chunks' kernels running beside them; "
                                  "stage_ms_one_chunk_in_flight / roofline: the same stages measured right after it with nothing beside them",
@@ -773,6 +833,7 @@ def main():
             # figures sit beside them under "timed_region".
             "roofline": {
                 "bound": "hbm",
+                "binding": "valu",  # what actually limits the kernel: vector-instruction issue (see "valu"); the HBM figures are the contract's
                 "kernel": kernels[dom],
                 "achieved": round(per_frame * B / (solo[dom] * 1e-3) / 1e9, 3),
                 "peak": HBM_PEAK_GBS,
@@ -796,6 +857,9 @@ def main():
                 "frac_of_peak": round(ab["total"] * value / world / 1e9 / HBM_PEAK_GBS, 6),
             },
             "pcie_inclusive": pcie,
+            "match_gpairs_per_s": None if args.no_match or match_ms <= 0 else round(pair_count / (match_ms * 1e-3) / 1e9, 3),
+            "single_call_ms": single_call,
+            "gather_ms": None if gather_ms is None else round(gather_ms, 4),
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(frames_np, nfeat)

@@ -22,8 +22,8 @@ namespace {
 constexpr int kCalibChains = 8;
 constexpr int kCalibUnroll = 16;
 
-enum CalibOp { OP_COUNT = 44 };
-const char* kOpNames[OP_COUNT] = {"v_add_u32", "v_pk_min_i16", "v_pk_sub_i16", "v_perm_b32", "v_bcnt_u32_b32", "v_dot4_u32_u8", "v_mul_lo_u32", "v_alignbyte_b32", "v_min3_i32", "v_xor_b32", "v_mad_u32_u24", "v_min_u16_sdwa", "v_lshlrev_b32(const)", "v_and_b32(sgpr)", "v_pk_min_u16", "v_pk_sub_u16_clamp", "v_and_or_b32", "v_mov_b32", "v_and_b32", "v_or_b32", "v_lshlrev_b32(vgpr)", "v_lshrrev_b32(const)", "v_min_u32", "v_max_i32", "v_max_u16", "v_sub_u16", "v_sub_u32", "v_add_u32(sgpr)", "v_add_u32(const)", "v_xor_b32(sgpr)", "v_cndmask_b32", "v_mul_u32_u24", "v_bfe_u32", "v_add3_u32", "v_lshl_add_u32", "v_lshl_or_b32", "v_sad_u8", "v_max_u16_sdwa(word)", "v_mov_b32_sdwa", "v_pk_add_u16", "v_pk_lshlrev_b16", "v_add_f32", "v_fma_f32", "v_cmp_lt_u32+cndmask"};
+enum CalibOp { OP_COUNT = 70 };
+const char* kOpNames[OP_COUNT] = {"v_add_u32", "v_pk_min_i16", "v_pk_sub_i16", "v_perm_b32", "v_bcnt_u32_b32", "v_dot4_u32_u8", "v_mul_lo_u32", "v_alignbyte_b32", "v_min3_i32", "v_xor_b32", "v_mad_u32_u24", "v_min_u16_sdwa", "v_lshlrev_b32(const)", "v_and_b32(sgpr)", "v_pk_min_u16", "v_pk_sub_u16_clamp", "v_and_or_b32", "v_mov_b32", "v_and_b32", "v_or_b32", "v_lshlrev_b32(vgpr)", "v_lshrrev_b32(const)", "v_min_u32", "v_max_i32", "v_max_u16", "v_sub_u16", "v_sub_u32", "v_add_u32(sgpr)", "v_add_u32(const)", "v_xor_b32(sgpr)", "v_cndmask_b32", "v_mul_u32_u24", "v_bfe_u32", "v_add3_u32", "v_lshl_add_u32", "v_lshl_or_b32", "v_sad_u8", "v_max_u16_sdwa(word)", "v_mov_b32_sdwa", "v_pk_add_u16", "v_pk_lshlrev_b16", "v_add_f32", "v_fma_f32", "v_cmp_lt_u32+cndmask", "v_min_u16", "v_add_u16", "v_max_i16", "v_lshlrev_b16", "v_lshrrev_b16", "v_ashrrev_i32", "v_not_b32", "v_subrev_u32", "v_max_u32", "v_min_i32", "v_mul_f32", "v_fmac_f32", "v_mul_hi_u32", "v_alignbit_b32", "v_bfi_b32", "v_or3_b32", "v_bitop3_b32", "v_mbcnt_lo_u32_b32", "v_cmp_lt_u32(vcc)", "v_cvt_f32_u32", "v_add_u32(literal)", "v_and_b32(literal)", "v_ffbl_b32", "v_bcnt(vop3 const)", "v_mov_b32_dpp", "v_readfirstlane+mov"};
 
 template <int OP>
 __device__ __forceinline__ void one(uint32_t& a, uint32_t b) {
@@ -71,6 +71,32 @@ __device__ __forceinline__ void one(uint32_t& a, uint32_t b) {
   if (OP == 41) asm volatile("v_add_f32 %0, %0, %1" : "+v"(a) : "v"(b));
   if (OP == 42) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(a) : "v"(b));
   if (OP == 43) asm volatile("v_cmp_lt_u32 vcc, %0, %1\n v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a) : "v"(b) : "vcc");
+  if (OP == 44) asm volatile("v_min_u16 %0, %0, %1" : "+v"(a) : "v"(b));
+  if (OP == 45) asm volatile("v_add_u16 %0, %0, %1" : "+v"(a) : "v"(b));
+  if (OP == 46) asm volatile("v_max_i16 %0, %0, %1" : "+v"(a) : "v"(b));
+  if (OP == 47) asm volatile("v_lshlrev_b16 %0, 1, %0" : "+v"(a) : "v"(b));
+  if (OP == 48) asm volatile("v_lshrrev_b16 %0, 1, %0" : "+v"(a) : "v"(b));
+  if (OP == 49) asm volatile("v_ashrrev_i32 %0, 1, %0" : "+v"(a) : "v"(b));
+  if (OP == 50) asm volatile("v_not_b32 %0, %1" : "+v"(a) : "v"(b));
+  if (OP == 51) asm volatile("v_subrev_u32 %0, %0, %1" : "+v"(a) : "v"(b));
+  if (OP == 52) asm volatile("v_max_u32 %0, %0, %1" : "+v"(a) : "v"(b));
+  if (OP == 53) asm volatile("v_min_i32 %0, %0, %1" : "+v"(a) : "v"(b));
+  if (OP == 54) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a) : "v"(b));
+  if (OP == 55) asm volatile("v_fmac_f32 %0, %1, %1" : "+v"(a) : "v"(b));
+  if (OP == 56) asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(a) : "v"(b));
+  if (OP == 57) asm volatile("v_alignbit_b32 %0, %0, %1, 16" : "+v"(a) : "v"(b));
+  if (OP == 58) asm volatile("v_bfi_b32 %0, %1, %0, %1" : "+v"(a) : "v"(b));
+  if (OP == 59) asm volatile("v_or3_b32 %0, %0, %1, %1" : "+v"(a) : "v"(b));
+  if (OP == 60) asm volatile("v_bitop3_b32 %0, %0, %1, %1 bitop3:0x80" : "+v"(a) : "v"(b));
+  if (OP == 61) asm volatile("v_mbcnt_lo_u32_b32 %0, %1, %0" : "+v"(a) : "v"(b));
+  if (OP == 62) asm volatile("v_cmp_lt_u32 vcc, %0, %1" : "+v"(a) : "v"(b) : "vcc");
+  if (OP == 63) asm volatile("v_cvt_f32_u32 %0, %0" : "+v"(a) : "v"(b));
+  if (OP == 64) asm volatile("v_add_u32 %0, 0x12345, %0" : "+v"(a) : "v"(b));
+  if (OP == 65) asm volatile("v_and_b32 %0, 0x7f7f7f7f, %0" : "+v"(a) : "v"(b));
+  if (OP == 66) asm volatile("v_ffbl_b32 %0, %0" : "+v"(a) : "v"(b));
+  if (OP == 67) asm volatile("v_bcnt_u32_b32 %0, %0, 0" : "+v"(a) : "v"(b));
+  if (OP == 68) asm volatile("v_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(a) : "v"(b));
+  if (OP == 69) asm volatile("v_readfirstlane_b32 s20, %0\n v_mov_b32 %0, s20" : "+v"(a) : "v"(b) : "s20");
 }
 
 template <int OP>
@@ -169,7 +195,7 @@ int orbx_debug_valu_calib(int op, int waves_per_simd, int iters, double out[3]) 
     orbx_internal_set_error("orbx_debug_valu_calib: allocation failed");
     return -3;
   }
-  void (*fn[OP_COUNT])(int, int, uint32_t*, unsigned long long*, hipStream_t) = {launch<0>, launch<1>, launch<2>, launch<3>, launch<4>, launch<5>, launch<6>, launch<7>, launch<8>, launch<9>, launch<10>, launch<11>, launch<12>, launch<13>, launch<14>, launch<15>, launch<16>, launch<17>, launch<18>, launch<19>, launch<20>, launch<21>, launch<22>, launch<23>, launch<24>, launch<25>, launch<26>, launch<27>, launch<28>, launch<29>, launch<30>, launch<31>, launch<32>, launch<33>, launch<34>, launch<35>, launch<36>, launch<37>, launch<38>, launch<39>, launch<40>, launch<41>, launch<42>, launch<43>};
+  void (*fn[OP_COUNT])(int, int, uint32_t*, unsigned long long*, hipStream_t) = {launch<0>, launch<1>, launch<2>, launch<3>, launch<4>, launch<5>, launch<6>, launch<7>, launch<8>, launch<9>, launch<10>, launch<11>, launch<12>, launch<13>, launch<14>, launch<15>, launch<16>, launch<17>, launch<18>, launch<19>, launch<20>, launch<21>, launch<22>, launch<23>, launch<24>, launch<25>, launch<26>, launch<27>, launch<28>, launch<29>, launch<30>, launch<31>, launch<32>, launch<33>, launch<34>, launch<35>, launch<36>, launch<37>, launch<38>, launch<39>, launch<40>, launch<41>, launch<42>, launch<43>, launch<44>, launch<45>, launch<46>, launch<47>, launch<48>, launch<49>, launch<50>, launch<51>, launch<52>, launch<53>, launch<54>, launch<55>, launch<56>, launch<57>, launch<58>, launch<59>, launch<60>, launch<61>, launch<62>, launch<63>, launch<64>, launch<65>, launch<66>, launch<67>, launch<68>, launch<69>};
   float best = 1e30f;
   for (int rep = 0; rep < 6; rep++) {
     hipEventRecord(e0, nullptr);

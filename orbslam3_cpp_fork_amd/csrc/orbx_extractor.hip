@@ -235,6 +235,7 @@ struct orbx_extractor {
     bool                   valid = false;
   };
   bool                       pyrLdsRaised[2] = {false, false};
+  bool                       pyrBandsOnly = false;  // a level's source footprint does not fit k_resize_level's LDS stage (scale factors above ~1.3): every call uses k_pyramid_bands
   PyrPlanHost                pyrLatency[2];  // calls with a handful of frames: levels [1, mid) and [mid, nlevels) as two launches
   std::vector<int2>          hYtab;  // host copy of the row tables (band ranges are derived from them)
   int buildPyrPlan(int firstLevel, int endLevel, int bandRows, int ldsLimit, PyrPlanHost& out);
@@ -340,8 +341,8 @@ int orbx_extractor::makeGeometry(int rows, int cols) {
     LevelGeom& L = g.lv[l];
     L.w = cvRoundF((float)cols * invSf[l]);  // src/ORBextractor.cc:1142-1143
     L.h = cvRoundF((float)rows * invSf[l]);
-    if (L.w < 2 * kMinBorder + 35 || L.h < 2 * kMinBorder + 35) {
-      g_err = "image too small for the pyramid depth: a level has less than one 35-px FAST cell";
+    if (L.w < 8 || L.h < 8) {
+      g_err = "image too small for the pyramid depth: a level is narrower than 8 px";
       return -2;
     }
     L.pitch = alignUp(L.w, 64);
@@ -358,8 +359,12 @@ int orbx_extractor::makeGeometry(int rows, int cols) {
     const float W      = 35;
     L.nCols            = (int)(width / W);
     L.nRows            = (int)(height / W);
-    L.wCell            = (int)std::ceil(width / L.nCols);
-    L.hCell            = (int)std::ceil(height / L.nRows);
+    // A level with less than one 35-px cell of usable area: the reference's cell loops do not execute (its wCell = ceil(width / 0) is
+    // never used), so the level contributes no keypoint.  It is still part of the pyramid chain and is blurred like any other.
+    const bool noCells = L.nCols <= 0 || L.nRows <= 0;
+    if (noCells) L.nCols = L.nRows = 0;
+    L.wCell            = noCells ? 0 : (int)std::ceil(width / L.nCols);
+    L.hCell            = noCells ? 0 : (int)std::ceil(height / L.nRows);
     if (L.wCell + 6 > kFastTileMax || L.hCell + 6 > kFastTileMax) {
       g_err = "FAST cell larger than the kernel tile";
       return -2;
@@ -386,12 +391,12 @@ int orbx_extractor::makeGeometry(int rows, int cols) {
     slotBase += L.slotCount;
     // quadtree (src/ORBextractor.cc:566-570)
     L.N    = quota[l];
-    L.nIni = (int)std::round(width / height);
+    L.nIni = noCells ? 1 : (int)std::round(width / height);
     if (L.nIni <= 0) {
       g_err = "portrait image with height > 2 x width: DistributeOctTree would divide by zero (nIni == 0)";
       return -2;
     }
-    L.hX       = width / L.nIni;
+    L.hX       = noCells ? 1.0f : width / L.nIni;
     L.nodeCap  = alignUp(std::max(L.N + 3, 4 * L.nIni) + 16, 16);
     if (L.nodeCap > kOtMaxNodes) {
       g_err = "more than 16383 quadtree nodes on one level is not supported";
@@ -424,7 +429,7 @@ int orbx_extractor::makeGeometry(int rows, int cols) {
   g.totalNodes     = nodeBase;
   g.totalKp        = kpBase;
   if (kpBase > orbx::kLayoutMaxRounds * 256) {
-    g_err = "more than 16384 keypoints per frame";
+    g_err = "more than 32768 keypoints per frame";
     return -2;
   }
   g.totalBlurTiles = tileBase;
@@ -580,6 +585,14 @@ int orbx_extractor::makeGeometry(int rows, int cols) {
   geom     = g;
   haveGeom = true;
   capB     = 0;  // workspace must be re-laid out
+  // k_resize_level stages the source footprint of a 128 x 16 destination tile in a fixed LDS block (176 x 24 source pixels): fine up to a
+  // scale factor of ~1.3 (every configuration the reference ships uses 1.2); above that the band kernel, which sizes its LDS from the
+  // tables, produces every level for batches as well
+  pyrBandsOnly = false;
+  for (int l = 1; l < g.nlevels; l++) {
+    const double sx = (double)g.lv[l - 1].w / g.lv[l].w, sy = (double)g.lv[l - 1].h / g.lv[l].h;
+    if (sx * kRsTileW + 6 > kRsLdsW || sy * (kRsTileH - 1) + 3 > kRsLdsH - 1) pyrBandsOnly = true;
+  }
   // fused pyramid launches of the latency form: the chain in two halves (shorter chains recompute fewer shared rows)
   hYtab = yt;
   pyrLatency[0].valid = pyrLatency[1].valid = false;
@@ -716,7 +729,7 @@ int orbx_extractor::run(const uint8_t* d_imgs, int B, int rows, int cols, size_t
     // batches: one launch per level.  A handful of frames: the chain in two launches of k_pyramid_bands (levels they do not cover -- a
     // plan that did not fit the LDS -- fall back to their own launches).
     int covered[2][2] = {{0, 0}, {0, 0}};
-    if (B <= octLatencyFrames)
+    if (B <= octLatencyFrames || pyrBandsOnly)
       for (int part = 0; part < 2; part++)
         if (pyrLatency[part].valid) covered[part][0] = pyrLatency[part].plan.firstLevel, covered[part][1] = pyrLatency[part].plan.endLevel;
     for (int l = 1; l < g.nlevels;) {
@@ -724,6 +737,10 @@ int orbx_extractor::run(const uint8_t* d_imgs, int B, int rows, int cols, size_t
       for (int q = 0; q < 2; q++)
         if (covered[q][0] == l && covered[q][1] > l) part = q;
       if (part < 0) {
+        if (pyrBandsOnly) {
+          g_err = "scale factor above ~1.3 on an image this wide: the pyramid band kernel's LDS plan does not fit";
+          return -2;
+        }
         const int tx = (g.lv[l].w + kRsTileW - 1) / kRsTileW, ty = (g.lv[l].h + kRsTileH - 1) / kRsTileH;
         hipLaunchKernelGGL(k_resize_level, dim3(8 * tx, ty, (B + 7) / 8), dim3(256), 0, s, b, g, l, B);
         l++;
@@ -751,7 +768,9 @@ int orbx_extractor::run(const uint8_t* d_imgs, int B, int rows, int cols, size_t
     static const int dbgEnv = getenv("ORBX_DBG_SKIP_FAST") ? atoi(getenv("ORBX_DBG_SKIP_FAST")) : 0;  // phase ablation (wrong results by design)
     dbg = dbgEnv;
 #endif
-    if (al4)
+    if (tileGrid == 0) {
+      // no level has a FAST cell: nothing to detect (the quadtree launch zeroes the counts)
+    } else if (al4)
       hipLaunchKernelGGL((k_fast_tiles<true>), dim3(tileGrid, B), dim3(kFastTileThreads), fastLds2.total, s, b, g, dTiles.p, dTileOrder.p, t1, t2, fastLds2, dbg);
     else
       hipLaunchKernelGGL((k_fast_tiles<false>), dim3(tileGrid, B), dim3(kFastTileThreads), fastLds2.total, s, b, g, dTiles.p, dTileOrder.p, t1, t2, fastLds2, dbg);

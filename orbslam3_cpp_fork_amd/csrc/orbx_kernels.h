@@ -437,6 +437,10 @@ __global__ __launch_bounds__(NT) void k_octree(Bufs b, FrameGeom g, int ldsNodeC
   octree_args(b, g, f, level, &a);
   // feed order: exclusive scan of the cell counts, then copy the slots
   const int  nc     = L.nCols * L.nRows;
+  if (nc == 0) {  // a level without a FAST cell (makeGeometry): no candidates, no keypoints
+    if (c.tid == 0) b.candCount[(long long)f * g.nlevels + level] = 0, *a.outCount = 0;
+    return;
+  }
   const int* counts = b.cellCount + (long long)f * g.totalCells + L.cellBase;
   int*       offs   = b.cellOffs + (long long)f * g.totalCells + L.cellBase;
   int        lo, hi;
@@ -495,7 +499,7 @@ __global__ __launch_bounds__(kOctThreads) void k_octree_only(OtArgs a) {
 // Keypoint i (natural order) is handled by thread i % 256 in round i / 256: every load of a round is independent of every other, and
 // the rank of a "stereo" keypoint (the number of them before it) is a ballot inside the wave plus a prefix over (round, wave) counts
 // held in LDS -- two short rounds over the keypoints instead of two dependent walks of a per-thread chunk.
-constexpr int kLayoutMaxRounds = 64;  // x 256 keypoints per frame (host-checked against totalKp)
+constexpr int kLayoutMaxRounds = 128;  // x 256 keypoints per frame (host-checked against totalKp)
 
 __global__ __launch_bounds__(256) void k_layout(Bufs b, FrameGeom g, int lap0, int lap1, int* counts, int cap) {
   __shared__ int sLbase[kMaxLevels + 1];
@@ -532,12 +536,13 @@ __global__ __launch_bounds__(256) void k_layout(Bufs b, FrameGeom g, int lap0, i
     if (lane == 0) sCnt[j * 4 + wave] = __popcll(bm);
   }
   __syncthreads();
-  if (wave == 0) {  // exclusive prefix over the rounds * 4 counts (<= 256 of them: four per lane)
-    const int m = rounds * 4;
-    int       v[4], sum = 0;
+  if (wave == 0) {  // exclusive prefix over the rounds * 4 counts (<= 512 of them: eight per lane)
+    constexpr int kPer = kLayoutMaxRounds * 4 / 64;
+    const int     m = rounds * 4;
+    int           v[kPer], sum = 0;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      v[k] = lane * 4 + k < m ? sCnt[lane * 4 + k] : 0;
+    for (int k = 0; k < kPer; k++) {
+      v[k] = lane * kPer + k < m ? sCnt[lane * kPer + k] : 0;
       sum += v[k];
     }
     int inc = sum;
@@ -548,8 +553,8 @@ __global__ __launch_bounds__(256) void k_layout(Bufs b, FrameGeom g, int lap0, i
     }
     int run = inc - sum;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      if (lane * 4 + k < m) sCnt[lane * 4 + k] = run;
+    for (int k = 0; k < kPer; k++) {
+      if (lane * kPer + k < m) sCnt[lane * kPer + k] = run;
       run += v[k];
     }
     if (lane == 63) sCnt[kLayoutMaxRounds * 4] = inc;  // total

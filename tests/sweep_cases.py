@@ -1,0 +1,48 @@
+"""Constructor / input parameter sweep shared by tests/test_gpu_param_sweep.py and tools/dbg_param_sweep.py.
+
+(rows, cols), nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, lapping area, strided input.  The reference's constructor takes all of
+these freely (src/ORBextractor.cc:403-465); the canonical pair (1.2, 8) is what every other test uses."""
+CASES = [
+    # nlevels
+    ((480, 640), 1000, 1.2, 1, 20, 7, (0, 0), False),
+    ((480, 640), 1000, 1.2, 2, 20, 7, (0, 1000), False),
+    ((480, 640), 1000, 1.2, 5, 20, 7, (0, 0), False),
+    ((1200, 1600), 3000, 1.2, 12, 20, 7, (0, 0), False),
+    # scale factors
+    ((480, 640), 1000, 1.1, 8, 20, 7, (0, 0), False),
+    ((1200, 1600), 2000, 1.1, 12, 20, 7, (0, 1000), False),
+    ((600, 800), 1000, 1.5, 5, 20, 7, (0, 0), False),
+    ((960, 1280), 1500, 2.0, 4, 20, 7, (0, 0), False),
+    ((480, 640), 500, 2.0, 2, 20, 7, (200, 400), False),
+    # feature counts
+    ((480, 640), 1, 1.2, 8, 20, 7, (0, 0), False),
+    ((480, 640), 30, 1.2, 8, 20, 7, (0, 1000), False),
+    ((480, 640), 20000, 1.2, 8, 20, 7, (0, 0), False),
+    ((1080, 1920), 20000, 1.2, 8, 20, 7, (0, 1000), False),
+    # thresholds
+    ((480, 640), 1000, 1.2, 8, 0, 0, (0, 0), False),
+    ((480, 640), 1000, 1.2, 8, 255, 255, (0, 0), False),
+    ((480, 640), 1000, 1.2, 8, 7, 20, (0, 0), False),
+    ((480, 640), 1000, 1.2, 8, 200, 1, (0, 0), False),
+    # sizes: a level without a FAST cell (both sides refuse with the same code), the smallest that works, strided, large
+    ((64, 96), 500, 1.2, 8, 20, 7, (0, 0), False),
+    ((67, 67), 100, 1.2, 1, 20, 7, (0, 0), False),
+    ((120, 160), 300, 1.2, 3, 20, 7, (0, 0), False),
+    ((240, 320), 500, 1.2, 8, 20, 7, (0, 0), False),
+    ((480, 640), 1000, 1.2, 8, 20, 7, (0, 0), True),
+    ((479, 637), 1000, 1.2, 8, 20, 7, (0, 1000), True),
+    ((3000, 4000), 5000, 1.2, 8, 20, 7, (0, 0), False),
+    ((2000, 3000), 2000, 1.5, 6, 20, 7, (0, 1000), False),
+]
+
+
+def sweep_image(h, w, strided):
+    """A textured test image of any size (crops of one synthetic world), optionally as a view with step > cols."""
+    from orbslam3_cpp_fork_amd import synth
+
+    H, W = h + (20 if strided else 0), w + (60 if strided else 0)
+    if H >= 240 and W >= 320:
+        img = synth.make_frame(H, W, 3, (h * 7 + w) % 23)
+    else:
+        img = synth.make_frame(480, 640, 3, (h * 7 + w) % 23)[100:100 + H, 150:150 + W].copy()
+    return img[10:10 + h, 30:30 + w] if strided else img

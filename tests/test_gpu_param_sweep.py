@@ -1,0 +1,43 @@
+"""Parity beyond the canonical (scaleFactor 1.2, nlevels 8): the reference's constructor takes its five parameters freely
+(src/ORBextractor.cc:403-465) and orbx_create accepts them, so the HIP path must equal the oracle for them too -- float bits of every
+keypoint field, every descriptor byte, the return value -- through BOTH forms of the extraction: the single synchronous call (latency form:
+band-fused pyramid, workgroup-per-problem quadtree) and the device batch (one resize launch per level, wave-per-problem quadtree)."""
+import numpy as np
+import pytest
+
+from tests.sweep_cases import CASES, sweep_image
+
+
+def _id(case):
+    (h, w), nf, sf, nl, ini, mn, lap, strided = case
+    return "%dx%d-nf%d-sf%g-L%d-th%d_%d-lap%d_%d%s" % (w, h, nf, sf, nl, ini, mn, lap[0], lap[1], "-strided" if strided else "")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CASES, ids=_id)
+def test_extractor_parameter_sweep(oracle, case):
+    import torch
+
+    from orbslam3_cpp_fork_amd.extractor import ORBextractor
+
+    (h, w), nf, sf, nl, ini, mn, lap, strided = case
+    img = sweep_image(h, w, strided)
+    rc0, k0, d0 = oracle.OracleExtractor(nf, sf, nl, ini, mn)(img, lap)
+    gex = ORBextractor(nf, sf, nl, ini, mn)
+    rc, k, d = gex(img, None, lap)
+    assert rc == rc0 and len(k) == len(k0), (rc, rc0, len(k), len(k0))
+    assert (k.view(np.uint32) == k0.view(np.uint32)).all() and (d == d0).all()
+    if h * w > 1300 * 1700:
+        return
+    B, cap, n = 9, gex.max_keypoints(h, w), len(k0)
+    dimg = torch.from_numpy(np.ascontiguousarray(img)).cuda().unsqueeze(0).repeat(B, 1, 1).contiguous()
+    kps = torch.zeros((B, cap, 7), device="cuda")
+    desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
+    cnt = torch.zeros((B, 2), dtype=torch.int32, device="cuda")
+    gex.extract_batch_device(dimg, B, h, w, w, h * w, kps, desc, cnt, cap, lap, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    kk, dd, cc = kps.cpu().numpy().view(np.uint32), desc.cpu().numpy(), cnt.cpu().numpy()
+    for f in (0, 4, 8):
+        assert cc[f, 0] == n and cc[f, 1] == rc0, (f, cc[f], n, rc0)
+        assert (kk[f, :n] == k0.view(np.uint32).reshape(n, 7)).all() and (dd[f, :n] == d0).all(), "batch form, frame %d" % f
+    gex.close()

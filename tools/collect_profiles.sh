@@ -14,8 +14,8 @@ cd /tmp && export TMPDIR=/tmp
 # The default command keeps 3 chunks in flight: its kernel durations contain the share of the other chunks' kernels running beside them
 # (trace_default = the summary the bench line's roofline.avg_launch_ms must agree with).  Everything that prices ONE kernel -- solo
 # duration, HBM bytes, VALU instructions -- is collected with one chunk in flight.
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_default -- python3 $R/bench.py --no-cpu-baseline --no-pcie > $OUT/bench_trace_default.log 2>&1 || echo "step failed (rc $?)"
-B="--no-cpu-baseline --no-pcie --lanes 1"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_default -- python3 $R/bench.py --no-cpu-baseline --no-pcie --no-single-call > $OUT/bench_trace_default.log 2>&1 || echo "step failed (rc $?)"
+B="--no-cpu-baseline --no-pcie --no-single-call --lanes 1"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py $B > $OUT/bench_trace.log 2>&1 || echo "step failed (rc $?)"
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py --steps 3 --warmup 1 $B > $OUT/bench_fetch.log 2>&1 || echo "step failed (rc $?)"
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py --steps 3 --warmup 1 $B > $OUT/bench_write.log 2>&1 || echo "step failed (rc $?)"

@@ -2,9 +2,9 @@
 """tools/collect_profiles.sh output directory -> per kernel: VALU wave-instructions per launch (SQ_INSTS_VALU summed over the waves of
 a dispatch), achieved wave-instructions per second (/ the rocprof average duration of the SAME command's kernel-trace pass) and the
 fraction of the MEASURED issue ceiling (tools/valu_calibrate.py; no residency constants, no clamps).  The ceiling depends on the
-encoding class: 32-bit-encoded VOP1 / VOP2 / VOPC instructions issue at ~1.0 per ns per SIMD, 64-bit-encoded VOP3 / VOP3P ones
-(everything packed, three-operand or with an SGPR / literal operand in the wrong slot) at ~0.58; the static share of the two classes in
-each kernel's code object (tools/isa_blocks.py counts) gives the kernel's own ceiling 1 / (f2 / R2 + f3 / R3).  Also the L2 hit rate."""
+rate class of the instructions (tools/valu_mix.py: full rate ~1.07 per ns per SIMD for plain VGPR / inline-constant VOP2 forms of the
+opcodes that measure so, half rate ~0.59 for everything else); the static share of the two classes in each kernel's code object gives
+the kernel's own ceiling 1 / (f_full / R_full + f_half / R_half).  Also the L2 hit rate.  Usage: valu_summary.py <dir> [mix.json]"""
 import collections
 import csv
 import glob
@@ -38,17 +38,16 @@ f = one(d + "/pmc_tcc/*/*counter_collection.csv")
 if f:
     for r in csv.DictReader(open(f)):
         tcc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
-mix = {}
-try:
-    mix = json.load(open(d + "/../../profiles/r02_valu_mix.json"))
-except Exception:
-    try:
-        import os
+import os
 
-        mix = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r02_valu_mix.json")))
+mix = {}
+for cand in ([sys.argv[2]] if len(sys.argv) > 2 else []) + [os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r03_valu_mix.json")]:
+    try:
+        mix = json.load(open(cand))
+        break
     except Exception:
-        mix = {}
-out = {"calibration": {"vop2_ginst_per_s": r2, "vop3_ginst_per_s": r3, "peak_ginst_per_s": r3, "source": "tools/valu_calibrate.py (csrc/orbx_calib.hip), same box, same run"},
+        pass
+out = {"calibration": {"full_rate_ginst_per_s": r2, "half_rate_ginst_per_s": r3, "peak_ginst_per_s": r2, "source": "tools/valu_calibrate.py (csrc/orbx_calib.hip), same box, same run"},
        "kernels": {}}
 for k, c in agg.items():
     if not k.startswith("k_") or k not in summ["kernels"] or "avg_ms" not in summ["kernels"][k]:
@@ -56,10 +55,10 @@ for k, c in agg.items():
     m = {n: sum(v) / len(v) for n, v in c.items()}
     ms = summ["kernels"][k]["avg_ms"]
     g = m["SQ_INSTS_VALU"] / (ms * 1e-3) / 1e9
-    f3 = mix.get(k, {}).get("vop3_share")
+    f3 = mix.get(k, {}).get("half_rate_share")
     ceil_k = 1.0 / ((1 - f3) / r2 + f3 / r3) if f3 is not None else r3
     e = {"avg_ms": round(ms, 5), "valu_insts_per_launch": m["SQ_INSTS_VALU"], "waves": m.get("SQ_WAVES"), "valu_ginst_per_s": round(g, 2),
-         "vop3_share_static": f3, "kernel_ceiling_ginst_per_s": round(ceil_k, 1), "valu_frac": round(g / ceil_k, 4),
+         "half_rate_share_static": f3, "kernel_ceiling_ginst_per_s": round(ceil_k, 1), "valu_frac": round(g / ceil_k, 4),
          "wave_cycles_per_wave": round(m.get("SQ_WAVE_CYCLES", 0) / max(m.get("SQ_WAVES", 1), 1), 1),
          "wait_any_share": round(m.get("SQ_WAIT_ANY", 0) / max(m.get("SQ_WAVE_CYCLES", 1), 1), 3),
          "wait_inst_any_share": round(m.get("SQ_WAIT_INST_ANY", 0) / max(m.get("SQ_WAVE_CYCLES", 1), 1), 3)}
