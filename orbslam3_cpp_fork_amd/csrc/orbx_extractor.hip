@@ -239,10 +239,10 @@ struct orbx_extractor {
   PyrPlanHost                pyrLatency[2];  // calls with a handful of frames: levels [1, mid) and [mid, nlevels) as two launches
   std::vector<int2>          hYtab;  // host copy of the row tables (band ranges are derived from them)
   int buildPyrPlan(int firstLevel, int endLevel, int bandRows, int ldsLimit, PyrPlanHost& out);
-  DevBuf<orbx::FastTile>     dTiles;      // k_fast_tiles: tile table + XCD-aware launch order
-  DevBuf<int>                dTileOrder;
-  int                        tileGrid = 0;
-  orbx::FastLds2             fastLds2{};
+  DevBuf<orbx::FastTile>     dTiles[2];      // k_fast_tiles: tile table + XCD-aware launch order; [0] batches, [1] a handful of frames
+  DevBuf<int>                dTileOrder[2];
+  int                        tileGrid[2] = {0, 0};
+  orbx::FastLds2             fastLds2[2] = {};
 
   // optional cv::resize of the input before extraction (System::TrackMonocular etc., src/System.cc:472-478)
   int          preW = 0, preH = 0, preSrcW = 0, preSrcH = 0;
@@ -435,12 +435,16 @@ int orbx_extractor::makeGeometry(int rows, int cols) {
   g.totalBlurTiles = tileBase;
   g.pyrBytes       = alignUp(pyrOff, 256);
   g.blurBytes      = alignUp(blurOff, 256);
-  // ---- k_fast_tiles: tiles = runs of horizontally adjacent valid cells of one cell row (orbx_fast_tiles.h)
-  {
+  // ---- k_fast_tiles: tiles = runs of horizontally adjacent valid cells of one cell row (orbx_fast_tiles.h).  Two tilings of the same cells:
+  // [0] for batches (8 KB of pixels per tile: the per-workgroup costs are paid once per ~4 cells), [1] for calls with a handful of frames
+  // (4 KB: twice as many, shorter workgroups -- a single frame's 150 large tiles leave 100 CUs idle and the launch lasts as long as one
+  // tile's whole chain of phases)
+  for (int set = 0; set < 2; set++) {
     auto magic = [](unsigned d) { return d <= 1 ? 0u : 0xffffffffu / d + 1u; };
-    int                    kTileBudget = 8192;  // LDS bytes of one pixel tile
+    int                    kTileBudget = set == 0 ? 8192 : 4096;  // LDS bytes of one pixel tile (latency form measured at 2.5 / 3 / 4 / 6 / 8 KB: 10.6 / 10.8 / 10.4 / 12.3 / 27.7 us per VGA frame)
 #ifdef ORBX_TUNING
-    if (getenv("ORBX_FAST_TILE_BYTES")) kTileBudget = atoi(getenv("ORBX_FAST_TILE_BYTES"));
+    if (getenv("ORBX_FAST_TILE_BYTES") && set == 0) kTileBudget = atoi(getenv("ORBX_FAST_TILE_BYTES"));
+    if (getenv("ORBX_FAST_TILE_BYTES_LATENCY") && set == 1) kTileBudget = atoi(getenv("ORBX_FAST_TILE_BYTES_LATENCY"));
 #endif
     std::vector<FastTile>  tiles;
     struct RowRef {
@@ -535,10 +539,10 @@ int orbx_extractor::makeGeometry(int rows, int cols) {
     std::vector<int> order(per * 8, -1);
     for (int x = 0; x < 8; x++)
       for (size_t k = 0; k < perXcd[x].size(); k++) order[k * 8 + x] = perXcd[x][k];
-    tileGrid = (int)order.size();
-    if (dTiles.ensure(tiles.size() + 1) || dTileOrder.ensure(order.size() + 1)) return -3;
-    HIP_TRY(hipMemcpy(dTiles.p, tiles.data(), tiles.size() * sizeof(FastTile), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(dTileOrder.p, order.data(), order.size() * sizeof(int), hipMemcpyHostToDevice));
+    tileGrid[set] = (int)order.size();
+    if (dTiles[set].ensure(tiles.size() + 1) || dTileOrder[set].ensure(order.size() + 1)) return -3;
+    HIP_TRY(hipMemcpy(dTiles[set].p, tiles.data(), tiles.size() * sizeof(FastTile), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dTileOrder[set].p, order.data(), order.size() * sizeof(int), hipMemcpyHostToDevice));
     // LDS plan
     const int region = alignUp(maxTileBytes + 32, 16);
     FastLds2  fl{};
@@ -557,7 +561,7 @@ int orbx_extractor::makeGeometry(int rows, int cols) {
       g_err = "FAST tile LDS plan exceeds 160 KB";
       return -2;
     }
-    fastLds2 = fl;
+    fastLds2[set] = fl;
   }
   // upload tables
   if (dXtab.ensure(xt.size() + 1) || dYtab.ensure(yt.size() + 1) || dCellSlot.ensure(cellSlot.size() + 1)) return -3;
@@ -768,12 +772,13 @@ int orbx_extractor::run(const uint8_t* d_imgs, int B, int rows, int cols, size_t
     static const int dbgEnv = getenv("ORBX_DBG_SKIP_FAST") ? atoi(getenv("ORBX_DBG_SKIP_FAST")) : 0;  // phase ablation (wrong results by design)
     dbg = dbgEnv;
 #endif
-    if (tileGrid == 0) {
+    const int ts = B <= octLatencyFrames ? 1 : 0;  // tiling: short tiles for a handful of frames
+    if (tileGrid[ts] == 0) {
       // no level has a FAST cell: nothing to detect (the quadtree launch zeroes the counts)
     } else if (al4)
-      hipLaunchKernelGGL((k_fast_tiles<true>), dim3(tileGrid, B), dim3(kFastTileThreads), fastLds2.total, s, b, g, dTiles.p, dTileOrder.p, t1, t2, fastLds2, dbg);
+      hipLaunchKernelGGL((k_fast_tiles<true>), dim3(tileGrid[ts], B), dim3(kFastTileThreads), fastLds2[ts].total, s, b, g, dTiles[ts].p, dTileOrder[ts].p, t1, t2, fastLds2[ts], dbg);
     else
-      hipLaunchKernelGGL((k_fast_tiles<false>), dim3(tileGrid, B), dim3(kFastTileThreads), fastLds2.total, s, b, g, dTiles.p, dTileOrder.p, t1, t2, fastLds2, dbg);
+      hipLaunchKernelGGL((k_fast_tiles<false>), dim3(tileGrid[ts], B), dim3(kFastTileThreads), fastLds2[ts].total, s, b, g, dTiles[ts].p, dTileOrder[ts].p, t1, t2, fastLds2[ts], dbg);
   }
   if (prof) HIP_TRY(hipEventRecord(ev[2], s));
   // level-major grid: the large levels start first and every level spreads over all XCDs
@@ -911,7 +916,7 @@ static void release_device_side(orbx_extractor* h) {
     for (auto& slot : h->ev)
       for (auto& e : slot) hipEventDestroy(e);
   h->dPyr.release(), h->dBlur.release(), h->dStereoSad.release(), h->dStereoRowStart.release(), h->dStereoRowIdx.release(), h->sSad.release(), h->sKept.release(), h->sRow.release(), h->sRidx.release(), h->sKl.release(), h->sKr.release(), h->sDl.release(), h->sDr.release(), h->sU.release(), h->sDepth.release(), h->dRaw.release(), h->dPre.release(), h->dPreX.release(), h->dPreY.release(), h->dStage.release(), h->dDescOut.release(), h->dOutBlock.release(), h->dXtab.release(), h->dYtab.release();
-  h->pyrLatency[0].dBands.release(), h->pyrLatency[1].dBands.release(), h->dTiles.release(), h->dTileOrder.release(), h->dCellSlot.release(), h->dCellCount.release(), h->dNodeOf.release(), h->dCellOffs.release();
+  h->pyrLatency[0].dBands.release(), h->pyrLatency[1].dBands.release(), h->dTiles[0].release(), h->dTiles[1].release(), h->dTileOrder[0].release(), h->dTileOrder[1].release(), h->dCellSlot.release(), h->dCellCount.release(), h->dNodeOf.release(), h->dCellOffs.release();
   h->dD.release(), h->dDIndex.release(), h->dNCh.release(), h->dPushOff.release(), h->dMultiOff.release();
   h->dKeptRank.release(), h->dVA.release(), h->dVB.release(), h->dCandCount.release(), h->dLvlCount.release(), h->dOutIdx.release();
   h->dCounts.release(), h->dSlots.release(), h->dCand.release(), h->dLvlKp.release(), h->dNodesA.release(), h->dNodesB.release();
