@@ -746,6 +746,16 @@ def main():
                 ex1(img, None, (0, 1000))
                 ts.append(time.perf_counter() - t1)
             single_call["%dx%d/%d" % (w1, h1, nf1)] = round(float(np.median(ts[8:])) * 1e3, 4)
+            if (h1, w1) == (376, 1241):
+                # what the C++ adaptor's default costs on the stereo path: levels >= 1 of the pyramid ride home inside the call
+                # (orbx_set_pyramid_download; an unchanged Frame::ComputeStereoMatches reads mvImagePyramid, src/Frame.cc:1039-1058)
+                ex1.set_pyramid_download(True)
+                ts = []
+                for i in range(48):
+                    t1 = time.perf_counter()
+                    ex1(img, None, (0, 0))
+                    ts.append(time.perf_counter() - t1)
+                single_call["%dx%d/%d+pyramid_to_host" % (w1, h1, nf1)] = round(float(np.median(ts[8:])) * 1e3, 4)
             ex1.close()
 
     if rank == 0:

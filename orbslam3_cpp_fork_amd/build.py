@@ -36,7 +36,7 @@ def source_digest():
         if os.path.exists(path):
             h.update(f.encode() + b"\0" + open(path, "rb").read())
     h.update(open(os.path.abspath(__file__), "rb").read())
-    h.update(repr((HIPFLAGS, CXXFLAGS, _tuning())).encode())
+    h.update(repr((HIPFLAGS, CXXFLAGS, _tuning(), os.environ.get("ORBX_TUNING_DEFINES", "") if _tuning() else "")).encode())
     return h.hexdigest()
 
 
@@ -52,7 +52,7 @@ def build(force=False, verbose=False):
     if not force and not _stale():
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    extra = ["-DORBX_TUNING"] if _tuning() else []
+    extra = (["-DORBX_TUNING"] + os.environ.get("ORBX_TUNING_DEFINES", "").split()) if _tuning() else []  # e.g. ORBX_TUNING_DEFINES="-DORBX_MF_VARIANT=2"
     bdir = os.path.join(HERE, "_build")
     os.makedirs(bdir, exist_ok=True)
     objs = []

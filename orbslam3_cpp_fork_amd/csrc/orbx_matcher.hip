@@ -265,163 +265,12 @@ __global__ __launch_bounds__(256) void k_group_topk(GroupArgs a0) {
   }
 }
 
-// Brute-force form of the top-K pass (one group, identity index lists -- the per-frame stream case): one QUERY per
-// lane, the train descriptors walk by as LDS broadcasts (every lane reads the same address), so a candidate costs 8 xor + 8
-// popcount-accumulate per lane and nothing else; the sorted per-lane K-list is only touched for the rare candidate
-// below the pruning bound.  k_group_topk (one wave per query, lanes stride the candidates) stays for the grouped
-// DBoW2 form, whose candidate lists are short and differ per query.
-constexpr int kBfTile = 256;  // train rows staged in LDS per step (8 KB)
+// Brute-force form of the top-K pass (one group, identity index lists -- the per-frame stream case): orbx_bf_mfma.h (the distance matrix
+// of a frame pair as an int8 GEMM on the matrix cores).  k_group_topk (one wave per query, lanes stride the candidates, popcounts) stays
+// for the grouped DBoW2 form, whose candidate lists are short and differ per query.
+constexpr int kBfQueue = 16;  // hits a lane may park between two merges
 
-// popcount with accumulate, pinned: left to itself the compiler turns the 8-term sum into independent popcounts plus an
-// add tree (11 VALU per distance); the accumulate operand of v_bcnt makes it 8, and four rows in flight hide the chain.
-__device__ __forceinline__ int popc0(uint32_t x) {
-  int r;
-  asm("v_bcnt_u32_b32 %0, %1, 0" : "=v"(r) : "v"(x));
-  return r;
-}
-__device__ __forceinline__ int popc_acc(uint32_t x, int acc) {
-  int r;
-  asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
-  return r;
-}
-
-constexpr int kBfQueue     = 16;  // hits a lane may park between two merges
-constexpr int kBfFlushRows = 64;  // rows between two scheduled merges (power of two, multiple of 4)
-
-// (A form that reads the rows into scalar registers instead -- wave-uniform s_load_dwordx8 from the constant address space, no LDS
-// tile -- was measured at 233 us against 205 us for this one on 256 x 1000 x 1000; so was splitting the rows over twice the waves.)
-template <bool TVALID>
-__global__ __launch_bounds__(256) void k_bf_topk(GroupArgs a0) {
-  __shared__ __align__(16) uint4 tile[2][kBfTile][2];  // double-buffered train descriptors
-  __shared__ uint8_t             tval[2][TVALID ? kBfTile : 1];
-  __shared__ uint32_t            hitq[kBfQueue][256];  // parked hits, slot-major (conflict-free)
-  const GroupArgs a   = pair_view(a0, blockIdx.y);
-  const int       tid = threadIdx.x;
-  const int       nq  = a.d_nq ? *a.d_nq : a.nq;
-  const int       nt  = a.d_nt ? *a.d_nt : a.nt;
-  if ((int)blockIdx.x * 256 >= nq) return;  // whole workgroup
-  const int  e      = blockIdx.x * 256 + tid;
-  const bool active = e < nq && !(a.q_valid && !a.q_valid[e]);
-  uint4      a0v = make_uint4(0, 0, 0, 0), a1v = a0v;
-  if (e < nq) {
-    a0v = *reinterpret_cast<const uint4*>(a.q + (size_t)e * 32);
-    a1v = *reinterpret_cast<const uint4*>(a.q + (size_t)e * 32 + 16);
-  }
-  uint32_t k[kTopK];
-#pragma unroll
-  for (int j = 0; j < kTopK; j++) k[j] = kEmpty;
-  int       cnt = 0;
-  const int dstar = a.dstar;
-  // A hit (distance under the pruning bound) is rare per LANE (a few dozen per query) but some lane of the wave hits in most
-  // rows, so merging every hit into the sorted list on the spot makes the whole wave execute the 8-deep insertion for
-  // ~3/4 of all rows.  Hits are parked in LDS instead and all lanes merge theirs together every kBfFlushRows rows -- the loop
-  // runs for the busiest lane's count -- or earlier when a lane's slots run low.  Parking is kept to three vector instructions:
-  // the lane's next free slot is held as a byte offset (slot * 1024 + tid * 4, so the hit count is offset >> 10), the pruning bound is a
-  // per-lane value (0 for a lane without a query: no distance is below it), and the row number enters as a scalar operand.
-  unsigned char* const hitqBytes = reinterpret_cast<unsigned char*>(&hitq[0][0]);
-  int                  dlane     = active ? dstar : 0;
-  bool                 tightened = false;
-  uint32_t             qslot     = tid * 4;
-  const uint32_t       qlimit    = (uint32_t)(kBfQueue - 4) * 1024u + (uint32_t)tid * 4u;  // above this a lane could overflow within four rows
-  auto park = [&](int row, int d) {
-    if (d < dlane) {
-      *reinterpret_cast<uint32_t*>(hitqBytes + qslot) = ((uint32_t)d << kPosBits) | (uint32_t)row;
-      qslot += 1024;
-    }
-  };
-  auto flush = [&]() {
-    const int qn = (int)(qslot >> 10);
-    for (int i = 0; __ballot(i < qn) != 0ull; i++) {
-      uint32_t key = i < qn ? hitq[i][tid] : kEmpty;  // kEmpty falls through the network without touching the list
-#pragma unroll
-      for (int j = 0; j < kTopK; j++) {
-        const uint32_t lo = min(key, k[j]);
-        key               = max(key, k[j]);
-        k[j]              = lo;
-      }
-    }
-    cnt += qn;
-    qslot = tid * 4;
-    // Once the K-list is full, a later row (= a larger position) only enters it with a distance below the list's last one: the
-    // lane's bound shrinks to that distance and everything at or above it is no longer parked.  Hits skipped this way are not
-    // counted, so a lane that has tightened its bound reports "more candidates than listed" (all the resolve pass asks of nvalid).
-    if (k[kTopK - 1] != kEmpty) {
-      const int dLast = (int)(k[kTopK - 1] >> kPosBits);
-      if (dLast < dlane) dlane = dLast, tightened = true;
-    }
-  };
-  // stage tile 0
-  auto stage = [&](int buf, int base) {
-    const int row = base + tid;
-    if (row < nt) {
-      tile[buf][tid][0] = *reinterpret_cast<const uint4*>(a.t + (size_t)row * 32);
-      tile[buf][tid][1] = *reinterpret_cast<const uint4*>(a.t + (size_t)row * 32 + 16);
-      if (TVALID) tval[buf][tid] = a.t_valid[row];
-    }
-  };
-  // four distances at once, their popcount chains interleaved word by word (four independent dependency chains in flight)
-  auto dist4 = [&](const uint4 (&b)[8], int (&d)[4]) {
-#pragma unroll
-    for (int j = 0; j < 4; j++) d[j] = popc0(a0v.x ^ b[2 * j].x);
-#pragma unroll
-    for (int j = 0; j < 4; j++) d[j] = popc_acc(a0v.y ^ b[2 * j].y, d[j]);
-#pragma unroll
-    for (int j = 0; j < 4; j++) d[j] = popc_acc(a0v.z ^ b[2 * j].z, d[j]);
-#pragma unroll
-    for (int j = 0; j < 4; j++) d[j] = popc_acc(a0v.w ^ b[2 * j].w, d[j]);
-#pragma unroll
-    for (int j = 0; j < 4; j++) d[j] = popc_acc(a1v.x ^ b[2 * j + 1].x, d[j]);
-#pragma unroll
-    for (int j = 0; j < 4; j++) d[j] = popc_acc(a1v.y ^ b[2 * j + 1].y, d[j]);
-#pragma unroll
-    for (int j = 0; j < 4; j++) d[j] = popc_acc(a1v.z ^ b[2 * j + 1].z, d[j]);
-#pragma unroll
-    for (int j = 0; j < 4; j++) d[j] = popc_acc(a1v.w ^ b[2 * j + 1].w, d[j]);
-  };
-  auto distw = [&](const uint4& b0, const uint4& b1) {
-    int d = popc0(a0v.x ^ b0.x);
-    d     = popc_acc(a0v.y ^ b0.y, d), d = popc_acc(a0v.z ^ b0.z, d), d = popc_acc(a0v.w ^ b0.w, d);
-    d     = popc_acc(a1v.x ^ b1.x, d), d = popc_acc(a1v.y ^ b1.y, d), d = popc_acc(a1v.z ^ b1.z, d);
-    return popc_acc(a1v.w ^ b1.w, d);
-  };
-  {
-    stage(0, 0);
-    __syncthreads();
-    int buf = 0;
-    for (int base = 0; base < nt; base += kBfTile) {
-      if (base + kBfTile < nt) stage(buf ^ 1, base + kBfTile);  // next tile in flight while this one is consumed
-      const int n = min(kBfTile, nt - base);
-      auto dist = [&](int r) { return distw(tile[buf][r][0], tile[buf][r][1]); };  // same LDS address in every lane: broadcast
-      auto consider = [&](int r, int d) {
-        if (!TVALID || tval[buf][r]) park(base + r, d);  // the flag is wave-uniform
-      };
-      // four rows per step: eight LDS reads and 64 xor/popcount in one straight block, one pruning test for all four
-      int r = 0;
-      for (; r + 4 <= n; r += 4) {
-        int   d[4];
-        uint4 bw[8];
-#pragma unroll
-        for (int j = 0; j < 4; j++) bw[2 * j] = tile[buf][r + j][0], bw[2 * j + 1] = tile[buf][r + j][1];
-        dist4(bw, d);
-        consider(r, d[0]), consider(r + 1, d[1]), consider(r + 2, d[2]), consider(r + 3, d[3]);
-        if ((r & (kBfFlushRows - 1)) == kBfFlushRows - 4 || __ballot(qslot > qlimit) != 0ull) flush();
-      }
-      for (; r < n; r++) {
-        consider(r, dist(r));
-        if (__ballot(qslot > qlimit) != 0ull) flush();
-      }
-      flush();
-      __syncthreads();
-      buf ^= 1;
-    }
-  }
-  if (e < nq) {
-    uint4* o = reinterpret_cast<uint4*>(a.topk + (size_t)e * kTopK);
-    o[0]     = make_uint4(k[0], k[1], k[2], k[3]);
-    o[1]     = make_uint4(k[4], k[5], k[6], k[7]);
-    a.nvalid[e] = tightened ? max(cnt, kTopK + 1) : cnt;
-  }
-}
+#include "orbx_bf_mfma.h"
 
 // Ordered claim resolution.  The reference walks the queries one by one and every accepted match removes its
 // train row from all later queries' candidate sets (src/ORBmatcher.cc:290-292, 337).  A query's outcome can
@@ -1471,9 +1320,9 @@ static int launch_groups(orbm_matcher* h, GroupArgs& a, int nq_cap, hipStream_t 
     if (a.q_idx || a.fvFeat)
       hipLaunchKernelGGL(k_group_topk, dim3((nqe + 3) / 4, npairs), dim3(256), 0, s, a);
     else if (a.t_valid)
-      hipLaunchKernelGGL(k_bf_topk<true>, dim3((nqe + 255) / 256, npairs), dim3(256), 0, s, a);
+      hipLaunchKernelGGL(k_bf_mfma<true>, dim3((nqe + kMfThreads / 2 - 1) / (kMfThreads / 2), npairs), dim3(kMfThreads), 0, s, a);
     else
-      hipLaunchKernelGGL(k_bf_topk<false>, dim3((nqe + 255) / 256, npairs), dim3(256), 0, s, a);
+      hipLaunchKernelGGL(k_bf_mfma<false>, dim3((nqe + kMfThreads / 2 - 1) / (kMfThreads / 2), npairs), dim3(kMfThreads), 0, s, a);
   }
   hipLaunchKernelGGL(k_group_resolve, dim3(npairs), dim3(kResolveThreads), 0, s, a);
   HIP_TRYM(hipGetLastError());
