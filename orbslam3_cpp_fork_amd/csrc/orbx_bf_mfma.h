@@ -34,6 +34,7 @@ __global__ __launch_bounds__(kMfThreads) void k_bf_mfma(GroupArgs a0) {
   __shared__ __align__(8) uint2    lut[256];
   __shared__ uint8_t               tval[2][TVALID ? kMfRows : 1];
   __shared__ uint32_t              hitq[kBfQueue][kMfThreads];  // parked hits, slot-major (conflict-free)
+  __shared__ short                 dots[16][kMfThreads];        // the 16 dot products of a lane's half tile, for the walk over its hit mask
   const GroupArgs a   = pair_view(a0, blockIdx.y);
   const int       tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
   const int       nq  = a.d_nq ? *a.d_nq : a.nq;
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(kMfThreads) void k_bf_mfma(GroupArgs a0) {
   bool                 tightened = false;
   uint32_t             qslot     = tid * 4;               // next free parking slot as a byte offset (slot * 4 kMfThreads + tid * 4)
   constexpr uint32_t   kSlotBytes = 4u * kMfThreads;
-  const uint32_t       qlimit    = (uint32_t)(kBfQueue - 4) * kSlotBytes + (uint32_t)tid * 4u;  // above this a lane could overflow within four registers
+  const uint32_t       qlimit    = (uint32_t)(kBfQueue - 1) * kSlotBytes + (uint32_t)tid * 4u;  // at or above the last slot: drain before the next hit
   auto flush = [&]() {
     const int qn = (int)(qslot / kSlotBytes);
     for (int i = 0; __ballot(i < qn) != 0ull; i++) {
@@ -144,22 +145,34 @@ __global__ __launch_bounds__(kMfThreads) void k_bf_mfma(GroupArgs a0) {
       asm volatile("" ::"v"(acc));
       continue;
 #endif
-      // ~3 % of all pairs of a real stream lie below the pruning bound (30 per query), so nearly every register of a half tile has a hit
-      // in SOME lane while a lane parks one every other half tile: merging after every half tile would run the 8-deep insertion for one
-      // key per lane at a time.  The queue is drained only when some lane could overflow within the next four registers.
+      // ~3 % of all pairs of a real stream lie below the pruning bound (30 per query): nearly every one of the 16 registers has a hit in
+      // SOME lane, while a lane has one in every other half tile.  Testing and parking register by register would run sixteen divergent
+      // blocks for two active lanes each; instead every lane collects a 16-bit hit mask (one compare and one shift-in per register), the
+      // dots go to a per-lane LDS scratch as 16-bit values, and the lanes then walk their OWN hits together: the loop runs for the busiest
+      // lane's count (2-3), each trip parking one hit per lane.
+      uint32_t hm = 0;
 #pragma unroll
-      for (int gq = 0; gq < 4; gq++) {
+      for (int g = 15; g >= 0; g--) {
+        const int dot = acc[g];
+        dots[g][tid] = (short)dot;
+        bool hit = dot > thr;
+        if (TVALID) hit = hit && tval[buf][32 * half + 4 * hh + (g & 3) + 8 * (g >> 2)];
+        hm = (hm << 1) | (hit ? 1u : 0u);
+      }
+      if (partial) {  // rows past the end of the train set (last tile only)
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-          const int g = 4 * gq + i, dot = acc[g], row = row0 + i + 8 * gq;
-          if (dot > thr && (!partial || row < nt) && (!TVALID || tval[buf][32 * half + 4 * hh + i + 8 * gq])) {
-#if defined(ORBX_MF_VARIANT) && (ORBX_MF_VARIANT & 8)
-            asm volatile("" ::"v"(row));
-#else
-            *reinterpret_cast<uint32_t*>(hitqBytes + qslot) = ((uint32_t)((256 - dot) >> 1) << kPosBits) | (uint32_t)row;
-            qslot += kSlotBytes;
+        for (int g = 0; g < 16; g++)
+          if (row0 + (g & 3) + 8 * (g >> 2) >= nt) hm &= ~(1u << g);
+      }
+      while (__ballot(hm != 0u) != 0ull) {
+        if (hm != 0u) {
+          const int g = __builtin_ctz(hm);
+          hm &= hm - 1u;
+          const int dot = dots[g][tid], row = row0 + (g & 3) + 8 * (g >> 2);
+#if !(defined(ORBX_MF_VARIANT) && (ORBX_MF_VARIANT & 8))
+          *reinterpret_cast<uint32_t*>(hitqBytes + qslot) = ((uint32_t)((256 - dot) >> 1) << kPosBits) | (uint32_t)row;
+          qslot += kSlotBytes;
 #endif
-          }
         }
 #if defined(ORBX_MF_VARIANT) && (ORBX_MF_VARIANT & 16)
         if (qslot > qlimit) qslot = tid * 4;  // never merge: the queue just wraps

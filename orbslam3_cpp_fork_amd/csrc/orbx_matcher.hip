@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256) void k_group_topk(GroupArgs a0) {
 // Brute-force form of the top-K pass (one group, identity index lists -- the per-frame stream case): orbx_bf_mfma.h (the distance matrix
 // of a frame pair as an int8 GEMM on the matrix cores).  k_group_topk (one wave per query, lanes stride the candidates, popcounts) stays
 // for the grouped DBoW2 form, whose candidate lists are short and differ per query.
-constexpr int kBfQueue = 16;  // hits a lane may park between two merges
+constexpr int kBfQueue = 8;   // hits a lane may park between two merges
 
 #include "orbx_bf_mfma.h"
 
