@@ -351,17 +351,21 @@ def run_stereo(args, c, rows, cols, nfeat):
             self.gl.close(), self.gr.close()
             _lib.lib().orbx_stream_destroy(self.st)
 
+    trace = (lambda m: print("bench.py[trace]: " + m, file=sys.stderr, flush=True)) if os.environ.get("ORBX_BENCH_TRACE") else (lambda m: None)
     lanes = [SLane() for _ in range(max(1, args.lanes))]
     nwarm = max(args.warmup, len(lanes))
     for i in range(nwarm):
         lanes[i % len(lanes)].step()
     fence(c)
+    trace("warm-up done")
     for ln in lanes:
         ln.gl.set_profiling(True)
     t0 = time.perf_counter()
     for i in range(args.steps):
         lanes[i % len(lanes)].step(timed=True)
+    trace("timed steps enqueued")
     fence(c)
+    trace("timed steps done")
     dt = max_over_ranks(c, time.perf_counter() - t0)
     # the stages with one chunk in flight (nothing beside them)
     ln = lanes[0]
@@ -369,10 +373,14 @@ def run_stereo(args, c, rows, cols, nfeat):
         x.gl.set_profiling(False)
     ln.gl.set_profiling(True)
     ln.ev = []
-    for _ in range(3):
+    for k in range(3):
         ln.step(timed=True)
         fence(c)
+        trace("solo step %d done" % k)
     gl, cl, kept, ev = ln.gl, ln.cl, ln.kept, ln.ev
+    faults = [(i, nm, f) for i, x in enumerate(lanes) for nm, f in (("left", x.gl.debug_fault()), ("right", x.gr.debug_fault())) if f]
+    if faults:  # a count a kernel consumes was out of range (orbx_debug_fault): the figures of this run are not to be trusted
+        print("bench.py: inconsistent counts on record: %s" % faults, file=sys.stderr, flush=True)
     if c.rank != 0:
         for x in lanes:
             x.close()
@@ -395,6 +403,7 @@ def run_stereo(args, c, rows, cols, nfeat):
                      "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
                      "algorithmic_bytes_per_launch": per_frame * B, "avg_launch_ms": round(stage[dom], 5)},
         "stage_ms_left_eye_one_chunk_in_flight": {k: round(v, 5) for k, v in stage.items()},
+        "count_faults": faults,
     }
     if c.world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(None, nfeat, warm=4, timed=60, stereo=(L, R, mb, mbf))
@@ -410,7 +419,7 @@ def run_stereo(args, c, rows, cols, nfeat):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=60, help="timed steps (60 x 256 frames = 15 360 frames, ~60 ms: long enough for the clocks to settle; 20 gave +-3 %% run to run)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=256, help="frames per step and per GPU, resident in HBM (rig workload: per step over ALL GPUs, 8 cameras x frames/8)")
     ap.add_argument("--workload", default="vga_stream_640x480_8lvl_1000feat_extract+match", choices=sorted(WORKLOADS))
@@ -627,6 +636,9 @@ def main():
         ln.ex.set_profiling(False)
     cnt = lanes[0].d_cnt.cpu().numpy()
     nm = lanes[0].d_nm.cpu().numpy()
+    faults = [(i, f) for i, x in enumerate(lanes) for f in (x.ex.debug_fault(),) if f]
+    if faults:
+        print("bench.py: inconsistent counts on record: %s" % faults, file=sys.stderr, flush=True)
     value = total_frames_per_step * args.steps / dt
     # the exchange step on its own (BASELINE.md config 5 asks for the gather latency): five gathers of lane 0's records, one at a time,
     # barrier before and a device synchronisation after each; maximum over the ranks of the median
@@ -870,6 +882,7 @@ def main():
             "match_gpairs_per_s": None if args.no_match or match_ms <= 0 else round(pair_count / (match_ms * 1e-3) / 1e9, 3),
             "single_call_ms": single_call,
             "gather_ms": None if gather_ms is None else round(gather_ms, 4),
+            "count_faults": faults,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(frames_np, nfeat)

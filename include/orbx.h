@@ -197,6 +197,13 @@ int orbx_debug_level_keypoints(orbx_t* h, int frame, int level, uint32_t* out, i
 int orbx_debug_octree_times(orbx_t* h, long long* out, int cap);
 /* PMC calibration: stream nbytes of scratch memory with `width` (1, 4 or 16) bytes per lane per load. */
 int orbx_debug_calib_read(orbx_t* h, long long nbytes, int width);
+/* Diagnosis: out[2 i], out[2 i + 1] = device address and size in bytes of the handle's i-th workspace buffer (names: tools/dbg_buffer_map.py);
+ * returns the number of buffers.  For matching a GPU memory-fault address with the allocation it lies behind. */
+int orbx_debug_buffers(orbx_t* h, unsigned long long* out, int cap);
+/* Counts that drive loops over device memory (FAST cell counts, per-level keypoint counts, the counts of a stereo batch) are clamped to
+ * the capacity of what they index; the first one that had to be is recorded: out = {code, frame, value, where} (codes: orbx_kernels.h).
+ * Returns 1 and clears the record if there is one, 0 if none (a healthy run), < 0 on error.  Synchronises the device. */
+int orbx_debug_fault(orbx_t* h, int out[4]);
 /* VALU issue-rate calibration (csrc/orbx_calib.hip): independent chains of one instruction class with waves_per_simd (1 .. 8) waves
  * resident per SIMD on every CU.  out = {nanoseconds of the launch, median shader cycles per wave, wave-instructions per wave};
  * orbx_debug_valu_calib_name(op) names the instruction (NULL past the last one).  Tuning hook: tools/valu_calibrate.py. */
@@ -207,6 +214,13 @@ const char* orbx_debug_valu_calib_name(int op);
 int orbx_debug_lds_calib(int width, int off, int waves_per_simd, int iters, double out[4]);
 /* Device run of DistributeOctTree alone on caller-supplied candidates (host arrays). */
 int orbx_debug_octree_device(orbx_t* h, const uint32_t* cand, int n, int W, int H, int N, uint32_t* out, int* out_count);
+/* The kernel's std::sort re-enactment alone (one wave) on n host records, in place: order = record >> 16, low 16 bits = payload;
+ * depth_limit < 0 = libstdc++'s own introsort depth limit, small values reach its heap-sort path on any input. */
+int orbx_debug_wave_sort(orbx_t* h, unsigned long long* records, int n, int depth_limit);
+/* orbx_debug_octree_device, keeping the records of every std::sort re-enactment of the run: sorts[0] = their number, then per sort 1 + 2 * 256 words
+ * (V, the V records before, the V records after); at most max_sorts are kept (sorts holds 1 + 513 * max_sorts words). */
+int orbx_debug_octree_sorts(orbx_t* h, const uint32_t* cand, int n, int W, int H, int N, uint32_t* out, int* out_count, unsigned long long* sorts,
+                            int max_sorts);
 
 /* ---- ORBmatcher ------------------------------------------------------------------------------ */
 

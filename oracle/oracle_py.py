@@ -20,8 +20,16 @@ assert KP_DTYPE.itemsize == 28
 
 def build(force=False):
     """Compile the oracle with g++ (oracle/Makefile)."""
-    if force or not os.path.exists(_SO):
-        subprocess.check_call(["make", "-C", _HERE] + (["-B"] if force else []), stdout=subprocess.DEVNULL)
+    import hashlib
+
+    # stale by content, not by mtime (the .so travels with the snapshot, and a copy may reorder timestamps)
+    digest = hashlib.sha256(b"".join(open(os.path.join(_HERE, f), "rb").read() for f in ("orb_oracle.cpp", "orb_oracle.h", "Makefile"))).hexdigest()
+    stamp = os.path.join(_HERE, "_build", "liborb_oracle.stamp")
+    have = open(stamp).read().strip() if os.path.exists(stamp) else ""
+    if force or not os.path.exists(_SO) or have != digest:
+        subprocess.check_call(["make", "-C", _HERE, "-B"], stdout=subprocess.DEVNULL)
+        with open(stamp, "w") as f:
+            f.write(digest)
     return _SO
 
 
@@ -226,6 +234,16 @@ def distribute_octtree(xs, ys, resp, min_x, max_x, min_y, max_y, n_target):
     if n < 0:
         return n, None
     return n, out[:n].copy()
+
+
+def std_sort(records):
+    """libstdc++'s std::sort on uint64 records ordered by (record >> 16); returns the sorted copy."""
+    r = np.ascontiguousarray(records, np.uint64).copy()
+    L = lib()
+    L.orao_std_sort.argtypes = [C.c_void_p, C.c_int]
+    L.orao_std_sort.restype = None
+    L.orao_std_sort(_p(r), len(r))
+    return r
 
 
 def libm_sincos_deg(deg):

@@ -833,6 +833,10 @@ int orao_distribute_octtree(const float* xs, const float* ys, const float* resp,
   return (int)out.size();
 }
 
+void orao_std_sort(unsigned long long* records, int n) {
+  std::sort(records, records + n, [](unsigned long long a, unsigned long long b) { return (a >> 16) < (b >> 16); });
+}
+
 void orao_libm_sincos_deg(const float* deg, int n, float* cos_out, float* sin_out) {
   for (int i = 0; i < n; i++) {
     float angle = deg[i] * factorPI;

@@ -74,6 +74,10 @@ void  orao_set_tap_contraction(orao_extractor_t*, int mode);
  * into the input arrays in output (list) order.  -2 if nIni == 0. */
 int orao_distribute_octtree(const float* xs, const float* ys, const float* resp, int n, int min_x, int max_x,
                             int min_y, int max_y, int n_target, int* out_idx, int cap);
+/* This host's std::sort (libstdc++) on n 64-bit records ordered by (record >> 16) -- the low 16 bits ride along --, as DistributeOctTree's
+ * sort of vPrevSizeAndPointerToNode (src/ORBextractor.cc:685) orders (size, UL.x) pairs.  std::sort is not stable: which of two equal
+ * keys comes first is the library's business, and the quadtree's result depends on it; this pins the port's re-enactment directly. */
+void orao_std_sort(unsigned long long* records, int n);
 /* libm (cosf, sinf) of this host for x = deg * (float)(CV_PI/180.f), as computeOrbDescriptor uses them
  * (src/ORBextractor.cc:93,97-98).  Bulk form for the exhaustive device-port check. */
 void orao_libm_sincos_deg(const float* deg, int n, float* cos_out, float* sin_out);

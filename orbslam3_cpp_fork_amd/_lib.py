@@ -64,10 +64,14 @@ SIGNATURES = {
     "orbx_debug_level_keypoints": (_i, [_vp, _i, _i, _vp, _i]),
     "orbx_debug_octree_times": (_i, [_vp, _vp, _i]),
     "orbx_debug_calib_read": (_i, [_vp, C.c_longlong, _i]),
+    "orbx_debug_buffers": (_i, [_vp, _vp, _i]),
+    "orbx_debug_fault": (_i, [_vp, _vp]),
     "orbx_debug_valu_calib": (_i, [_i, _i, _i, _vp]),
     "orbx_debug_valu_calib_name": (C.c_char_p, [_i]),
     "orbx_debug_lds_calib": (_i, [_i, _i, _i, _i, _vp]),
     "orbx_debug_octree_device": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _ip]),
+    "orbx_debug_wave_sort": (_i, [_vp, _vp, _i, _i]),
+    "orbx_debug_octree_sorts": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _ip, _vp, _i]),
     "orbm_create": (_i, [C.POINTER(_vp), _i]),
     "orbm_destroy": (None, [_vp]),
     "orbm_last_error": (C.c_char_p, []),

@@ -87,6 +87,7 @@ struct OtArgs {
   int*      outCount;
   long long* dbgT;  // optional diagnostic stamps (device tuning builds): [0] sort cycles, [1] total cycles, [2] division steps, [3] sorts,
                     // [4] cycles in the passes over the points, [5] per-node scans, [6] node rewrite, [7] root set-up
+  unsigned long long* dbgSort;  // optional (orbx_debug_octree_sorts): [0] = sorts so far; per sort 1 + 2 * 256 words: V, records before, records after
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -269,7 +270,7 @@ struct HostCtx {
 // walked serially: a partition's swaps are all found from two ballots per register slot (WaveSort::partition) and the
 // final insertion sort is a windowed stable rank (ot_wave_sort_r).  A single lane walking the library algorithm through
 // LDS needs ~2000 dependent LDS round trips (~100 us) for the ~100 nodes of a level; this needs ~60 wave instructions per
-// partition.  Falls back to the serial code if the heap-sort path would be taken.
+// partition.  (The heap-sort path of the library -- its depth limit -- is walked by one lane on the range it applies to.)
 // ------------------------------------------------------------------------------------------------
 template <int R>
 struct WaveSort {
@@ -367,16 +368,36 @@ struct WaveSort {
     return cut;
   }
 
-  __device__ __forceinline__ bool run(int n, int* stk, unsigned long long* scratch) {  // stk: 3 x 64 ints in LDS (wave-uniform work list)
+  // stk: 3 x 64 ints in LDS (wave-uniform work list); depth_limit < 0 -> the library's own 2 * floor(log2(n)) (tests pass small values)
+  __device__ __forceinline__ void run(int n, int* stk, unsigned long long* scratch, int depth_limit) {
     int lg = 0;
     while ((1 << (lg + 1)) <= n) lg++;
     int *sf = stk, *sl = stk + 64, *sd = stk + 128, sp = 0;
-    sf[0] = 0, sl[0] = n, sd[0] = 2 * lg, sp = 1;
+    sf[0] = 0, sl[0] = n, sd[0] = depth_limit < 0 ? 2 * lg : depth_limit, sp = 1;
     while (sp > 0) {
       --sp;
       int first = sf[sp], last = sl[sp], depth = sd[sp];
       while (last - first > 16) {
-        if (depth == 0) return false;
+        if (depth == 0) {
+          // the library's __partial_sort(first, last, last) = heap sort of this range, walked by one lane on the array as it stands
+          // (rare: 2 * log2(n) partitions without getting a range down to 16 records -- long runs of descending keys do it).  The
+          // records go through `scratch`, which holds nothing else between two partitions; a heap-sorted range is longer than 16
+          // records but already in its final order, which the windowed rank of ot_wave_sort_r leaves as it is.
+#pragma unroll
+          for (int s = 0; s < R; s++)
+            if (s * 64 + lane < n) scratch[s * 64 + lane] = v[s];
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          if (lane == 0) ot_heap_sort(scratch, first, last);
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int s = 0; s < R; s++)
+            if (s * 64 + lane < n) v[s] = scratch[s * 64 + lane];
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          break;
+        }
         --depth;
         // __move_median_to_first(first, first + 1, mid, last - 1)
         const int                mid = first + (last - first) / 2;
@@ -403,24 +424,24 @@ struct WaveSort {
       }
     }
     // __final_insertion_sort is done by the caller (ot_wave_sort_r): see there
-    return true;
   }
 };
 
 template <int R>
-__device__ __forceinline__ bool ot_wave_sort_r(unsigned long long* buf, int n, int* stk) {
+__device__ __forceinline__ void ot_wave_sort_r(unsigned long long* buf, int n, int* stk, int depth_limit) {
   const int   lane = threadIdx.x & 63;
   WaveSort<R> w;
   w.lane = lane;
 #pragma unroll
   for (int s = 0; s < R; s++) w.v[s] = (s * 64 + lane) < n ? buf[s * 64 + lane] : ~0ull;
-  if (!w.run(n, stk, buf)) return false;
+  w.run(n, stk, buf, depth_limit);
   // __final_insertion_sort (guarded insertion on the first 16 records, unguarded linear inserts after) without replaying its n
   // serial insertions.  An insertion sort never moves a record past an equal one, so its result is THE stable sort of the array the
   // introsort loop left behind; and that array is block-sorted -- every range the loop stopped on holds at most 16 records, all
   // records of an earlier range are <= all records of a later one -- so a record ends inside its own range, at most 15 places from
   // where it stands.  Hence: final position of record i = max(0, i - 15) + the number of records j of [i - 15, i + 15] with
-  // (key_j, j) < (key_i, i); every lane counts for its own records in parallel, then the records are scattered.
+  // (key_j, j) < (key_i, i); every lane counts for its own records in parallel, then the records are scattered.  (A range the loop
+  // heap-sorted instead may be longer, but it is in order already: the count then returns every record of it to where it stands.)
 #pragma unroll
   for (int s = 0; s < R; s++)
     if (s * 64 + lane < n) buf[s * 64 + lane] = w.v[s];
@@ -448,18 +469,17 @@ __device__ __forceinline__ bool ot_wave_sort_r(unsigned long long* buf, int n, i
     if (s * 64 + lane < n) buf[pos[s]] = w.v[s];
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
-  return true;
 }
 
-__device__ inline void ot_wave_sort(unsigned long long* buf, int n, int* stk) {  // called by ONE full wave; buf in LDS or global
-  bool done = false;
+__device__ inline void ot_wave_sort(unsigned long long* buf, int n, int* stk, int depth_limit = -1) {  // called by ONE full wave; buf in LDS or global
   if (n <= 64)
-    done = ot_wave_sort_r<1>(buf, n, stk);
+    ot_wave_sort_r<1>(buf, n, stk, depth_limit);
   else if (n <= 128)
-    done = ot_wave_sort_r<2>(buf, n, stk);
+    ot_wave_sort_r<2>(buf, n, stk, depth_limit);
   else if (n <= 256)
-    done = ot_wave_sort_r<4>(buf, n, stk);
-  if (!done && (threadIdx.x & 63) == 0) ot_std_sort(buf, n, -1, stk);  // large inputs / depth-limit case: the serial re-enactment
+    ot_wave_sort_r<4>(buf, n, stk, depth_limit);
+  else if ((threadIdx.x & 63) == 0)
+    ot_std_sort(buf, n, depth_limit, stk);  // large inputs: the serial re-enactment
 }
 
 struct DevCtx {
@@ -804,9 +824,22 @@ OT_HD inline void ot_distribute(CTX& c, const OtArgs& a) {
                          (unsigned long long)(unsigned)j;
         }
         c.sync();
+        if (a.dbgSort && V <= 256) {
+          unsigned long long* d = a.dbgSort + 1 + a.dbgSort[0] * 513;
+          if (c.tid == 0) d[0] = (unsigned long long)V;
+          for (int j = c.tid; j < V; j += c.nt) d[1 + j] = a.sortbuf[j];
+          c.sync();
+        }
         const long long t0 = OT_CLOCK();
         c.sort(a.sortbuf, V);
         c.sync();
+        if (a.dbgSort && V <= 256) {
+          unsigned long long* d = a.dbgSort + 1 + a.dbgSort[0] * 513;
+          for (int j = c.tid; j < V; j += c.nt) d[257 + j] = a.sortbuf[j];
+          c.sync();
+          if (c.tid == 0) a.dbgSort[0] += 1;
+          c.sync();
+        }
         if (a.dbgT && c.tid == 0) a.dbgT[0] += OT_CLOCK() - t0, a.dbgT[3] += 1;
         // processed from the back of the sorted vector (:686)
         for (int k = c.tid; k < V; k += c.nt) {
@@ -826,7 +859,10 @@ OT_HD inline void ot_distribute(CTX& c, const OtArgs& a) {
   for (int i = c.tid; i < n; i += c.nt)
     c.atomic_max(&a.best[a.nodeOf[i] & 0x3fff], ((unsigned long long)(unsigned)ot_cr(a.cand[i]) << 32) | (unsigned long long)(0xffffffffu - (unsigned)i));
   c.sync();
-  for (int i = c.tid; i < s.nNodes; i += c.nt) a.outKp[i] = a.cand[0xffffffffu - (unsigned)(c.atomic_load(&a.best[i]) & 0xffffffffull)];
+  for (int i = c.tid; i < s.nNodes; i += c.nt) {
+    const unsigned idx = 0xffffffffu - (unsigned)(c.atomic_load(&a.best[i]) & 0xffffffffull);
+    a.outKp[i]         = a.cand[idx < (unsigned)n ? idx : 0u];  // every node holds a point; the bound only fences off memory
+  }
   if (c.tid == 0) *a.outCount = s.nNodes;
   if (a.dbgT && c.tid == 0) a.dbgT[1] += OT_CLOCK() - tStart;
   c.sync();

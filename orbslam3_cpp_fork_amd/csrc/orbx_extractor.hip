@@ -195,6 +195,7 @@ struct orbx_extractor {
   DevBuf<float>   sU, sDepth;
   DevBuf<int2>    dXtab, dYtab;
     DevBuf<long long> dDbgT;
+  DevBuf<int>       dFault;  // Bufs::fault
   DevBuf<int>     dCellSlot, dCellCount, dCellOffs, dCandCount, dLvlCount, dCounts;
   DevBuf<int4>    dOutIdx;
   DevBuf<uint16_t> dNodeOf, dD, dDIndex, dPushOff, dMultiOff, dKeptRank, dVA, dVB;
@@ -651,12 +652,10 @@ int orbx_extractor::runResized(const uint8_t* d_imgs, int B, int rows, int cols,
     const int    pitch = alignUp(cols, 64);
     const size_t fs    = (size_t)pitch * rows;
     if (dPre.ensure(fs * B + 256)) return -3;
-    if (frameStride == step * (size_t)rows) {
-      HIP_TRY(hipMemcpy2DAsync(dPre.p, pitch, d_imgs, step, cols, (size_t)rows * B, hipMemcpyDeviceToDevice, s));
-    } else {
-      for (int f = 0; f < B; f++)
-        HIP_TRY(hipMemcpy2DAsync(dPre.p + fs * f, pitch, d_imgs + frameStride * f, step, cols, rows, hipMemcpyDeviceToDevice, s));
-    }
+    // an own kernel, not hipMemcpy2DAsync: the runtime's rectangle copy on several CU-masked streams at once was the one operation the
+    // stereo workload (the only one with unaligned rows) had that the others had not, when it met intermittent GPU memory faults with
+    // three chunks in flight
+    hipLaunchKernelGGL(k_repitch, dim3((cols + 1023) / 1024, rows, B), dim3(256), 0, s, d_imgs, (long long)step, (long long)frameStride, dPre.p, pitch, (long long)fs, cols, rows);
     return run(dPre.p, B, rows, cols, pitch, fs, lap0, lap1, d_kps, d_desc, d_counts, cap, s);
   }
   // footprint of a 128 x 16 destination tile must fit the LDS stage of resize_tile (176 x 24 source pixels)
@@ -688,7 +687,8 @@ int orbx_extractor::run(const uint8_t* d_imgs, int B, int rows, int cols, size_t
   if (rc) return rc;
   const FrameGeom& g = geom;
   Bufs             b = bufs;
-  b.dbgT = nullptr;
+  b.dbgT  = nullptr;
+  b.fault = dFault.p;
 #ifdef ORBX_TUNING
   if (getenv("ORBX_DBG_OCT")) {  // quadtree phase stamps (orbx_debug_octree_times)
     if (dDbgT.ensure((size_t)B * g.nlevels * 8)) return -3;
@@ -860,7 +860,7 @@ int orbx_create(orbx_t** out, int nfeatures, float scale_factor, int nlevels, in
     delete h;
     return -3;
   }
-  if (h->dPattern.ensure(1)) {
+  if (h->dPattern.ensure(1) || h->dFault.ensure(4) || hipMemset(h->dFault.p, 0, 16) != hipSuccess) {
     delete h;
     return -3;
   }
@@ -920,7 +920,7 @@ static void release_device_side(orbx_extractor* h) {
   h->dD.release(), h->dDIndex.release(), h->dNCh.release(), h->dPushOff.release(), h->dMultiOff.release();
   h->dKeptRank.release(), h->dVA.release(), h->dVB.release(), h->dCandCount.release(), h->dLvlCount.release(), h->dOutIdx.release();
   h->dCounts.release(), h->dSlots.release(), h->dCand.release(), h->dLvlKp.release(), h->dNodesA.release(), h->dNodesB.release();
-  h->dChildCnt.release(), h->dChildIdx.release(), h->dPattern.release(), h->dKpOut.release();
+  h->dChildCnt.release(), h->dChildIdx.release(), h->dPattern.release(), h->dKpOut.release(), h->dFault.release();
   h->stream = nullptr, h->graphExec = nullptr, h->hOut = h->hIn = h->hPyr = nullptr, h->hOutCap = h->hInCap = h->hPyrCap = 0, h->sIn = h->sOut = nullptr;
   for (auto& sl : h->slots) sl.evIn = sl.evCompute = sl.evDone = nullptr, sl.hIn = sl.hOut = nullptr, sl.hInCap = sl.hOutCap = 0;
   h->evValid = false, h->haveGeom = false, h->capB = 0;
@@ -1114,7 +1114,7 @@ int orbx_extract(orbx_t* h, const uint8_t* img, int rows, int cols, size_t step_
       HIP_TRY(hipMemcpyAsync(h->dStage.p, hsrc, rawBytes, hipMemcpyHostToDevice, h->stream));
     } else {
       HIP_TRY(hipMemcpyAsync(h->dRaw.p, hsrc, rawBytes, hipMemcpyHostToDevice, h->stream));
-      HIP_TRY(hipMemcpy2DAsync(h->dStage.p, pitch, h->dRaw.p, step_bytes, cols, rows, hipMemcpyDeviceToDevice, h->stream));
+      hipLaunchKernelGGL(orbx::k_repitch, dim3((cols + 1023) / 1024, rows, 1), dim3(256), 0, h->stream, h->dRaw.p, (long long)step_bytes, 0ll, h->dStage.p, pitch, 0ll, cols, rows);
     }
     const int rc2 = h->runResized(h->dStage.p, 1, rows, cols, pitch, (size_t)pitch * rows, lap0, lap1, reinterpret_cast<orbx::KpRec*>(dKpP), dDescP, dCountsP, need, h->stream);
     if (rc2) return rc2;
@@ -1478,8 +1478,15 @@ int orbx_debug_level_keypoints(orbx_t* h, int frame, int level, uint32_t* out, i
 }
 
 int orbx_debug_octree_device(orbx_t* h, const uint32_t* cand, int n, int W, int H, int N, uint32_t* out, int* out_count) {
+  return orbx_debug_octree_sorts(h, cand, n, W, H, N, out, out_count, nullptr, 0);
+}
+
+// The same, and the records of every std::sort re-enactment of the run as the kernel saw them: sorts[0] = their number, then per sort
+// 1 + 2 * 256 words (V, the V records before, the V records after); max_sorts bounds what is kept.  Diagnosis hook (tools/dbg_octree67.py).
+int orbx_debug_octree_sorts(orbx_t* h, const uint32_t* cand, int n, int W, int H, int N, uint32_t* out, int* out_count, unsigned long long* sorts,
+                            int max_sorts) {
   using namespace orbx;
-  if (!h || n < 0 || W <= 0 || H <= 0 || N < 0) return -2;
+  if (!h || n < 0 || W <= 0 || H <= 0 || N < 0 || max_sorts < 0) return -2;
   unsigned long long scratchEpoch = 0;  // the temporaries below are not the handle's: they retire nobody's graph
   EpochScope         es(&scratchEpoch);
   HIP_TRY(hipSetDevice(h->device));
@@ -1494,7 +1501,9 @@ int orbx_debug_octree_device(orbx_t* h, const uint32_t* cand, int n, int W, int 
   DevBuf<OtNode>             nodesA, nodesB;
   DevBuf<Int4>               sc;
   DevBuf<Idx4>               ec;
-  DevBuf<unsigned long long> sb, bst;
+  DevBuf<unsigned long long> sb, bst, dsort;
+  const size_t               sortWords = sorts ? 1 + (size_t)max_sorts * 513 + 513 : 0;
+  if (sorts && (dsort.ensure(sortWords) || hipMemset(dsort.p, 0, sortWords * 8) != hipSuccess)) return -3;
   if (dc.ensure(np) || dout.ensure(nn) || nA.ensure(np) || bst.ensure(nn) ||
       nodesA.ensure(nn) || nodesB.ensure(nn) || sc.ensure(nn) || ec.ensure(nn) || D.ensure(nn) || dI.ensure(nn) ||
       nCh.ensure(nn) || pO.ensure(nn) || mO.ensure(nn) || kR.ensure(nn) || vA.ensure(nn) || vB.ensure(nn) || sb.ensure(nn) || cnt.ensure(1))
@@ -1507,6 +1516,7 @@ int orbx_debug_octree_device(orbx_t* h, const uint32_t* cand, int n, int W, int 
   a.nodeOf = nA.p, a.best = bst.p, a.nodesA = nodesA.p, a.nodesB = nodesB.p;
   a.childCnt = sc.p, a.childIdx = ec.p, a.D = D.p, a.dIndex = dI.p, a.nCh = nCh.p, a.pushOff = pO.p, a.multiOff = mO.p, a.keptRank = kR.p;
   a.vA = vA.p, a.vB = vB.p, a.sortbuf = sb.p, a.outKp = dout.p, a.outCount = cnt.p;
+  a.dbgSort = sorts ? dsort.p : nullptr;
   hipLaunchKernelGGL(k_octree_only, dim3(1), dim3(kOctThreads), 0, h->stream, a);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(h->stream));
@@ -1514,9 +1524,32 @@ int orbx_debug_octree_device(orbx_t* h, const uint32_t* cand, int n, int W, int 
   HIP_TRY(hipMemcpy(&c, cnt.p, sizeof(int), hipMemcpyDeviceToHost));
   if (c > 0) HIP_TRY(hipMemcpy(out, dout.p, (size_t)c * 4, hipMemcpyDeviceToHost));
   if (out_count) *out_count = c;
+  if (sorts) HIP_TRY(hipMemcpy(sorts, dsort.p, (1 + (size_t)max_sorts * 513) * 8, hipMemcpyDeviceToHost));
+  dsort.release();
   dc.release(), dout.release(), nA.release(), bst.release(), D.release(), dI.release();
   nCh.release(), pO.release(), mO.release(), kR.release(), vA.release(), vB.release(), cnt.release(), nodesA.release();
   nodesB.release(), sc.release(), ec.release(), sb.release();
+  return 0;
+}
+
+// Parity hook: the kernel's std::sort re-enactment (ot_wave_sort, one wave) on n host records, in place; order = (record >> 16), the
+// low 16 bits are payload; depth_limit < 0 = the library's own (small values reach its heap-sort path on any input).  What
+// orbx_debug_std_sort (the host build of the library algorithm) is compared with.
+int orbx_debug_wave_sort(orbx_t* h, unsigned long long* records, int n, int depth_limit) {
+  using namespace orbx;
+  if (!h || !records || n < 0) return -2;
+  if (n == 0) return 0;
+  unsigned long long scratchEpoch = 0;
+  EpochScope         es(&scratchEpoch);
+  HIP_TRY(hipSetDevice(h->device));
+  DevBuf<unsigned long long> d;
+  if (d.ensure((size_t)n)) return -3;
+  HIP_TRY(hipMemcpy(d.p, records, (size_t)n * 8, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_wave_sort_only, dim3(1), dim3(64), 0, h->stream, d.p, n, depth_limit);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipMemcpy(records, d.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+  d.release();
   return 0;
 }
 
@@ -1663,9 +1696,11 @@ int orbx_stereo_matches_batch_device(orbx_t* left, orbx_t* right, const orbx_key
   EpochScope es(&left->allocEpoch);
   HIP_TRY(hipSetDevice(left->device));
   const bool byRow = left->geom.rows <= kStereoMaxRows;
+  const size_t hadIdx = left->dStereoRowIdx.n;
   if (left->dStereoSad.ensure((size_t)nframes * cap) ||
       (byRow && (left->dStereoRowStart.ensure((size_t)nframes * (left->geom.rows + 1) + 1) || left->dStereoRowIdx.ensure((size_t)nframes * cap))))
     return -3;
+  if (left->dStereoRowIdx.n != hadIdx) HIP_TRY(hipMemsetAsync(left->dStereoRowIdx.p, 0, left->dStereoRowIdx.n * sizeof(int), stream ? (hipStream_t)stream : left->stream));  // fresh memory holds no indices
   hipStream_t s = stream ? (hipStream_t)stream : left->stream;
   StereoArgs  a;
   memset(&a, 0, sizeof(a));
@@ -1673,6 +1708,7 @@ int orbx_stereo_matches_batch_device(orbx_t* left, orbx_t* right, const orbx_key
   a.pyrL0 = left->bufs.img0, a.pyrR0 = right->bufs.img0, a.pitch0 = left->bufs.img0Pitch;
   a.pyrL = left->bufs.pyr, a.pyrR = right->bufs.pyr, a.uRight = d_u_right, a.depth = d_depth, a.sad = left->dStereoSad.p;
   a.cap = cap, a.countsL = d_counts_l, a.countsR = d_counts_r, a.img0StrideL = left->bufs.img0FrameStride;
+  a.fault = left->dFault.p;
   a.img0StrideR = right->bufs.img0FrameStride, a.pyrBytes = left->geom.pyrBytes;
   if (byRow) {
     a.rowStart = left->dStereoRowStart.p, a.rowIdx = left->dStereoRowIdx.p, a.rowBand = (int)std::ceil(2.0f * left->sf[left->nlevels - 1]) + 1;
@@ -1682,6 +1718,38 @@ int orbx_stereo_matches_batch_device(orbx_t* left, orbx_t* right, const orbx_key
   hipLaunchKernelGGL(k_stereo_cut, dim3(nframes), dim3(256), 0, s, a, d_kept);
   HIP_TRY(hipGetLastError());
   return 0;
+}
+
+// The first inconsistent count a kernel of this handle met (checked_count in orbx_kernels.h): out = {code, frame, value, where}, code
+// 1 = FAST cell count above the cell's slot capacity, 2 = level keypoint count above its capacity, 3 / 4 = left / right keypoint count of
+// a stereo batch outside [0, cap].  Returns 1 if one is on record (and clears it), 0 if none, < 0 on error.  A healthy run never records one.
+int orbx_debug_fault(orbx_t* h, int out[4]) {
+  if (!h || !out) return -2;
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(out, h->dFault.p, 16, hipMemcpyDeviceToHost));
+  if (out[0] == 0) return 0;
+  HIP_TRY(hipMemset(h->dFault.p, 0, 16));
+  return 1;
+}
+
+// Diagnosis hook: (address, bytes) of the handle's device buffers, in the order of the name list in tools/dbg_buffer_map.py -- what a
+// "Memory access fault ... on address X" message is matched against.
+int orbx_debug_buffers(orbx_t* h, unsigned long long* out, int cap) {
+  if (!h || !out) return -2;
+  int n = 0;
+  auto put = [&](const void* p, size_t bytes) {
+    if (2 * n + 1 < cap) out[2 * n] = (unsigned long long)(uintptr_t)p, out[2 * n + 1] = (unsigned long long)bytes;
+    n++;
+  };
+#define ORBX_PUT(buf) put(h->buf.p, h->buf.n * sizeof(*h->buf.p))
+  ORBX_PUT(dPyr), ORBX_PUT(dBlur), ORBX_PUT(dPre), ORBX_PUT(dStage), ORBX_PUT(dSlots), ORBX_PUT(dCand), ORBX_PUT(dNodeOf), ORBX_PUT(dCellCount), ORBX_PUT(dCellOffs);
+  ORBX_PUT(dCandCount), ORBX_PUT(dLvlKp), ORBX_PUT(dLvlCount), ORBX_PUT(dOutIdx), ORBX_PUT(dNodesA), ORBX_PUT(dNodesB), ORBX_PUT(dChildCnt), ORBX_PUT(dChildIdx);
+  ORBX_PUT(dD), ORBX_PUT(dDIndex), ORBX_PUT(dNCh), ORBX_PUT(dPushOff), ORBX_PUT(dMultiOff), ORBX_PUT(dKeptRank), ORBX_PUT(dVA), ORBX_PUT(dVB);
+  ORBX_PUT(dStereoSad), ORBX_PUT(dStereoRowStart), ORBX_PUT(dStereoRowIdx), ORBX_PUT(dXtab), ORBX_PUT(dYtab), ORBX_PUT(dCellSlot), ORBX_PUT(dPattern);
+  ORBX_PUT(dTiles[0]), ORBX_PUT(dTiles[1]), ORBX_PUT(dTileOrder[0]), ORBX_PUT(dTileOrder[1]);
+#undef ORBX_PUT
+  return n;
 }
 
 // PMC calibration hook (see k_calib_read): reads `nbytes` of a scratch buffer with `width` bytes per lane per load.

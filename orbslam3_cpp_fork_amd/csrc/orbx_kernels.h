@@ -34,6 +34,7 @@ struct Bufs {
   long long      img0FrameStride;
   int            img0Pitch;
   long long*     dbgT;  // optional quadtree timing stamps [frame][level][8] (ORBX_DBG_OCT=1)
+  int*           fault; // [4] first inconsistency a kernel met in a count it consumes: {code, frame, value, where}; 0 = none (orbx_debug_fault)
   uint8_t*       pyr;   // [B][pyrBytes]   levels >= 1
   uint8_t*       blur;  // [B][blurBytes]  all levels
   const int2*    xtab;  // resize tables: .x = source index, .y = a0 | a1 << 16 (Q11)
@@ -60,6 +61,17 @@ struct Bufs {
   //          byte offset of the aligned 37 x 44 window origin in the frame's blurred block, scale (float bits), patch size}
   int4*               outIdx;
 };
+
+// A count that drives a loop over device memory is clamped to the capacity of what it indexes; the first one that had to be is put on
+// record instead of being walked (a garbage count would otherwise send a kernel across the end of its buffers).
+__device__ __forceinline__ int checked_count(int* fault, int code, int f, int where, int v, int cap) {
+  if (v < 0 || v > cap) {
+    if (fault && atomicCAS(&fault[0], 0, code) == 0) fault[1] = f, fault[2] = v, fault[3] = where;
+    return v < 0 ? 0 : cap;
+  }
+  return v;
+}
+enum { kFaultCellCount = 1, kFaultLevelCount = 2, kFaultStereoLeft = 3, kFaultStereoRight = 4 };
 
 __device__ __forceinline__ const uint8_t* level_raw(const Bufs& b, const FrameGeom& g, int level, int f, int* pitch) {
   if (level == 0) {
@@ -299,6 +311,25 @@ __global__ __launch_bounds__(kPyrBandThreads) void k_pyramid_bands(Bufs b, Frame
   }
 }
 
+// Rows that are not 4-byte aligned (odd widths with a tight step: KITTI's 1241) are copied once into a buffer with a 64-byte pitch, so
+// that every later pass reads aligned dwords.  One thread = 4 destination bytes of one row (an unaligned 32-bit load, an aligned store);
+// the columns past the image width are written too (they read the next bytes of the source, never past the frame's end + 3: the host
+// sizes its buffers with that slack, and the values are dead).
+__global__ __launch_bounds__(256) void k_repitch(const uint8_t* __restrict__ src, long long srcStep, long long srcFrameStride, uint8_t* __restrict__ dst, int dstPitch,
+                                                 long long dstFrameStride, int cols, int rows) {
+  const int x4 = (blockIdx.x * 256 + threadIdx.x) * 4, y = blockIdx.y, f = blockIdx.z;
+  if (x4 >= cols) return;
+  const uint8_t* p = src + (long long)f * srcFrameStride + (long long)y * srcStep + x4;
+  uint32_t       v;
+  if (x4 + 4 <= cols) {
+    __builtin_memcpy(&v, p, 4);
+  } else {  // the row's last, partial dword: byte loads, nothing is read past the row
+    v = 0;
+    for (int k = 0; x4 + k < cols; k++) v |= (uint32_t)p[k] << (8 * k);
+  }
+  *reinterpret_cast<uint32_t*>(dst + (long long)f * dstFrameStride + (long long)y * dstPitch + x4) = v;
+}
+
 // cv::resize(im, im, cv::Size(newWidth, newHeight)) of System::TrackMonocular / TrackStereo / TrackRGBD (src/System.cc:472-478 and
 // siblings) before the extractor sees the image: same arithmetic, any size pair.
 __global__ __launch_bounds__(256) void k_resize_input(const uint8_t* __restrict__ src, int sp, long long srcFrameStride, int sw, int sh,
@@ -445,14 +476,16 @@ __global__ __launch_bounds__(NT) void k_octree(Bufs b, FrameGeom g, int ldsNodeC
   int*       offs   = b.cellOffs + (long long)f * g.totalCells + L.cellBase;
   int        lo, hi;
   ot_chunk(c, nc, &lo, &hi);
+  const int* cslot0 = b.cellSlot + L.cellBase;
+  auto cellCount = [&](int i) { return checked_count(b.fault, kFaultCellCount, f, level * 65536 + i, counts[i], (i + 1 < nc ? cslot0[i + 1] : L.slotCount) - cslot0[i]); };
   Int4 loc = {{0, 0, 0, 0}};
-  for (int i = lo; i < hi; i++) loc.v[0] += counts[i];
+  for (int i = lo; i < hi; i++) loc.v[0] += cellCount(i);
   Int4 tot;
   Int4 ex  = c.scan4(loc, &tot);
   int  run = ex.v[0];
   for (int i = lo; i < hi; i++) {
     offs[i] = run;
-    run += counts[i];
+    run += cellCount(i);
   }
   c.sync();
   const int                    n     = tot.v[0];
@@ -460,7 +493,7 @@ __global__ __launch_bounds__(NT) void k_octree(Bufs b, FrameGeom g, int ldsNodeC
   const int*                   cslot = b.cellSlot + L.cellBase;
   uint32_t* __restrict__       cand  = b.cand + (long long)f * g.totalSlots + L.slotBase;
   for (int cidx = c.tid; cidx < nc; cidx += c.nt) {
-    const int cnt = counts[cidx], o = offs[cidx], sb = cslot[cidx];
+    const int cnt = cellCount(cidx), o = offs[cidx], sb = cslot[cidx];
 #pragma unroll 4
     for (int k = 0; k < cnt; k++) cand[o + k] = slots[sb + k];
   }
@@ -491,6 +524,12 @@ __global__ __launch_bounds__(kOctThreads) void k_octree_only(OtArgs a) {
   ot_distribute(c, a);
 }
 
+// the std::sort re-enactment of one wave on caller-supplied records (parity hook)
+__global__ __launch_bounds__(64) void k_wave_sort_only(unsigned long long* buf, int n, int depth_limit) {
+  __shared__ int stk[192];
+  ot_wave_sort(buf, n, stk, depth_limit);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Output layout of operator() (src/ORBextractor.cc:1090-1134): natural order is level-major / list
 // order; keypoints whose scaled x lies in [lap0, lap1] fill the output from the back, the others from
@@ -510,7 +549,7 @@ __global__ __launch_bounds__(256) void k_layout(Bufs b, FrameGeom g, int lap0, i
     int n0 = 0;
     for (int l = 0; l < g.nlevels; l++) {
       sLbase[l] = n0;
-      n0 += lc[l];
+      n0 += checked_count(b.fault, kFaultLevelCount, f, l, lc[l], g.lv[l].kpCap);
     }
     sLbase[g.nlevels] = n0;
   }
@@ -1034,6 +1073,7 @@ struct StereoArgs {
   // every iR whose band [floor(y - r), ceil(y + r)] holds v).  NULL = scan all right keypoints.
   int *rowStart, *rowIdx;
   int  rowBand;
+  int* fault;  // Bufs::fault of the left handle (checked_count)
 };
 
 constexpr int kStereoMaxRows = 4096;  // image rows the row index is built for (taller images scan all right keypoints)
@@ -1043,7 +1083,8 @@ __device__ __forceinline__ StereoArgs stereo_view(const StereoArgs& a, int f) {
   StereoArgs      v  = a;
   const long long fc = (long long)f * a.cap;
   v.kl = a.kl + fc, v.kr = a.kr + fc, v.dl = a.dl + fc * 32, v.dr = a.dr + fc * 32;
-  v.nl = a.countsL[2 * f], v.nr = a.countsR[2 * f];
+  v.nl = checked_count(a.fault, kFaultStereoLeft, f, 0, a.countsL[2 * f], a.cap);
+  v.nr = checked_count(a.fault, kFaultStereoRight, f, 0, a.countsR[2 * f], a.cap);
   v.pyrL0 = a.pyrL0 + f * a.img0StrideL, v.pyrR0 = a.pyrR0 + f * a.img0StrideR;
   v.pyrL = a.pyrL + f * a.pyrBytes, v.pyrR = a.pyrR + f * a.pyrBytes;
   v.uRight = a.uRight + fc, v.depth = a.depth + fc, v.sad = a.sad + fc;
@@ -1087,7 +1128,8 @@ __global__ __launch_bounds__(256) void k_stereo_rows(StereoArgs a0) {
   }
   if (tid == 255) a.rowStart[nrows] = a.nr;
   __syncthreads();
-  for (int i = tid; i < a.nr; i += 256) a.rowIdx[atomicAdd(&hist[min(max((int)a.kr[i].y, 0), nrows - 1)], 1)] = i;
+  // (the slot is clamped: should the keypoints change between the two passes -- they must not -- a row's cursor cannot leave the list)
+  for (int i = tid; i < a.nr; i += 256) a.rowIdx[min(atomicAdd(&hist[min(max((int)a.kr[i].y, 0), nrows - 1)], 1), a.nr - 1)] = i;
 }
 
 __global__ __launch_bounds__(256) void k_stereo_match(StereoArgs a0, FrameGeom g) {
@@ -1095,7 +1137,7 @@ __global__ __launch_bounds__(256) void k_stereo_match(StereoArgs a0, FrameGeom g
   const int        iL = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (iL >= a.nl) return;
   const KpRec kpL    = a.kl[iL];
-  const int   levelL = kpL.octave;
+  const int   levelL = min(max(kpL.octave, 0), g.nlevels - 1);  // (records are the extractor's own; the clamps here and below only fence off memory)
   const float vL = kpL.y, uL = kpL.x;
   const float minD = 0.f, maxD = a.mbf / a.mb;
   const float minU = uL - maxD, maxU = uL - minD;
@@ -1113,9 +1155,9 @@ __global__ __launch_bounds__(256) void k_stereo_match(StereoArgs a0, FrameGeom g
       pHi           = in ? a.rowStart[min(rowL + a.rowBand + 1, a.nrows)] : 0;
     }
     for (int p = pLo + lane; p < pHi; p += 64) {
-      const int   iR   = byRow ? a.rowIdx[p] : p;
+      const int   iR   = byRow ? min(max(a.rowIdx[p], 0), a.nr - 1) : p;  // an index read from memory never leaves the keypoint list
       const KpRec kpR  = a.kr[iR];
-      const float r    = 2.0f * g.lv[kpR.octave].scale;
+      const float r    = 2.0f * g.lv[min(max(kpR.octave, 0), g.nlevels - 1)].scale;
       const int   maxr = (int)ceilf(kpR.y + r), minr = (int)floorf(kpR.y - r);
       if (rowL < minr || rowL > maxr || rowL < 0 || rowL >= a.nrows) continue;
       if (kpR.octave < levelL - 1 || kpR.octave > levelL + 1) continue;
@@ -1146,10 +1188,12 @@ __global__ __launch_bounds__(256) void k_stereo_match(StereoArgs a0, FrameGeom g
         imL = a.pyrL + g.lv[levelL].pyrOff, imR = a.pyrR + g.lv[levelL].pyrOff, pitch = g.lv[levelL].pitch;
       }
       const int y0 = (int)(scaledvL - w), xl0 = (int)(scaleduL - w), xr0 = (int)(scaleduR0 - w);
-      int       acc[11];
+      // keypoints lie >= 19 px inside their level, so the 11 x 11 window and its +-5 shifts do too; a record that does not say so is skipped
+      const bool inside = y0 >= 0 && y0 + 11 <= g.lv[levelL].h && xl0 >= 0 && xl0 + 11 <= g.lv[levelL].w && xr0 - 5 >= 0 && xr0 + 16 <= g.lv[levelL].w;
+      int        acc[11];
 #pragma unroll
       for (int k = 0; k < 11; k++) acc[k] = 0;
-      for (int p = lane; p < 121; p += 64) {
+      for (int p = lane; inside && p < 121; p += 64) {
         const int yy = p / 11, xx = p - yy * 11;
         const int vl = imL[(long long)(y0 + yy) * pitch + xl0 + xx];
         const uint8_t* rr = imR + (long long)(y0 + yy) * pitch + xr0 + xx;
@@ -1171,7 +1215,7 @@ __global__ __launch_bounds__(256) void k_stereo_match(StereoArgs a0, FrameGeom g
         }
         vDists[k] = dist;
       }
-      if (!(bestinc == -Ls || bestinc == Ls)) {
+      if (inside && !(bestinc == -Ls || bestinc == Ls)) {
         float dist1 = 0.f, dist2 = 0.f, dist3 = 0.f;
 #pragma unroll
         for (int k = 1; k < 10; k++)

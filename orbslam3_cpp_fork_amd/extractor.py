@@ -182,6 +182,12 @@ class ORBextractor:
         check(_lib.lib().orbx_debug_octree_device(self._h, ptr(cand), len(cand), W, H, N, ptr(out), C.byref(cnt)), "octree_device")
         return out[: cnt.value].copy()
 
+    def debug_fault(self):
+        """orbx_debug_fault: None, or (code, frame, value, where) of the first inconsistent count a kernel met since the last query."""
+        out = (C.c_int * 4)()
+        rc = check(_lib.lib().orbx_debug_fault(self._h, out), "orbx_debug_fault")
+        return tuple(out) if rc == 1 else None
+
     def set_profiling(self, enable=True):
         _lib.lib().orbx_set_profiling(self._h, int(enable))
 

@@ -135,6 +135,35 @@ def test_std_sort_reenactment():
             assert sorted(buf.tolist()) == sorted(rec.tolist())
 
 
+def test_std_sort_reenactment_is_libstdcxx(oracle):
+    """ot_std_sort (host build of the re-enactment the kernel follows) against the real std::sort (oracle.std_sort) record for record --
+    equal keys included, and on inputs that drive introsort into its depth limit (the heap-sort path)."""
+    from orbslam3_cpp_fork_amd import _lib
+
+    L = _lib.lib()
+    from tests.sort_patterns import sort_patterns
+
+    for rec in sort_patterns(np.random.default_rng(11)):
+        mine = rec.copy()
+        L.orbx_debug_std_sort(mine.ctypes.data_as(C.c_void_p), len(mine), -1)
+        assert (mine == oracle.std_sort(rec)).all(), (len(rec), rec[:8].tolist())
+
+
+def test_octree_depth_limit_case(oracle):
+    """Level 0 of a KITTI-sized frame with 456 candidates for 434 wanted corners (golden fixture: the frame of the stereo bench the
+    device quadtree once got wrong): its third ordered pass sorts 57 nodes whose keys run mostly downhill, and libstdc++'s introsort
+    hits its depth limit on them.  Host model = oracle here; the device form is checked in tests/test_gpu_extractor.py."""
+    from orbslam3_cpp_fork_amd.extractor import octree_host_model
+
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "octree_depth_limit_case.npz"))
+    xs, ys, rs = (d["cand"][i].astype(np.int32) for i in range(3))
+    W, H, N = int(d["W"]), int(d["H"]), int(d["N"])
+    n1, idx = oracle.distribute_octtree(xs, ys, rs, 16, 16 + W, 16, 16 + H, N)
+    rc, out = octree_host_model(xs, ys, rs, W, H, N)
+    exp = xs[idx].astype(np.uint32) | (ys[idx].astype(np.uint32) << 12) | (rs[idx].astype(np.uint32) << 24)
+    assert rc == 0 and n1 == 434 and (out == exp).all()
+
+
 def test_sincos_port_exhaustive(oracle):
     """The glibc sinf/cosf port the kernel uses equals this host's libm for EVERY float angle in [0, 360] degrees
     (1,135,869,953 inputs), in both evaluation orders (plain and FMA-contracted)."""

@@ -1,4 +1,6 @@
 """GPU parity tests (run with -m gpu on an MI355X): HIP path through the C ABI vs the CPU oracle."""
+import os
+
 import numpy as np
 import pytest
 
@@ -109,6 +111,69 @@ def test_octree_device_random(oracle, gpu_ex):
         out = gpu_ex.debug_octree_device(px, py, rs, W, H, N)
         exp = px[idx].astype(np.uint32) | (py[idx].astype(np.uint32) << 12) | (rs[idx].astype(np.uint32) << 24)
         assert len(out) == n1 and (out == exp).all(), trial
+
+
+def test_wave_sort_is_std_sort(oracle, gpu_ex):
+    """The wave-parallel std::sort re-enactment (ot_wave_sort) against the host build of the library algorithm (pinned against the real
+    std::sort in tests/test_abi_and_hostmodel.py): every record in the same place, for tie-heavy, descending and median-of-3-hostile
+    inputs, and with depth limits 0..3 that force the heap-sort path on every range."""
+    import ctypes as C
+
+    from orbslam3_cpp_fork_amd import _lib
+    from tests.sort_patterns import sort_patterns
+
+    L = _lib.lib()
+    checked = 0
+    for rec in sort_patterns(np.random.default_rng(5)):
+        for depth in ((-1, 0, 1, 2, 3) if len(rec) <= 257 else (-1,)):
+            ref, got = rec.copy(), rec.copy()
+            L.orbx_debug_std_sort(ref.ctypes.data_as(C.c_void_p), len(ref), depth)
+            assert L.orbx_debug_wave_sort(gpu_ex._h, got.ctypes.data_as(C.c_void_p), len(got), depth) == 0
+            assert (ref == got).all(), (len(rec), depth, np.nonzero(ref != got)[0][:8].tolist())
+            if depth == -1:
+                assert (oracle.std_sort(rec) == got).all()
+            checked += 1
+    assert checked > 500
+
+
+def test_octree_depth_limit_case_device(oracle, gpu_ex):
+    """tests/golden/octree_depth_limit_case.npz on the device (stand-alone quadtree), twice: = the oracle, and the same both times."""
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "octree_depth_limit_case.npz"))
+    xs, ys, rs = (d["cand"][i].astype(np.int32) for i in range(3))
+    W, H, N = int(d["W"]), int(d["H"]), int(d["N"])
+    n1, idx = oracle.distribute_octtree(xs, ys, rs, 16, 16 + W, 16, 16 + H, N)
+    exp = xs[idx].astype(np.uint32) | (ys[idx].astype(np.uint32) << 12) | (rs[idx].astype(np.uint32) << 24)
+    for _ in range(2):
+        out = gpu_ex.debug_octree_device(xs, ys, rs, W, H, N)
+        assert len(out) == n1 and (out == exp).all()
+
+
+def test_sparse_level_frame(oracle):
+    """The whole frame that fixture comes from (left eye of pair 67 of the stereo bench: level 0 has barely more candidates than wanted
+    corners), single and inside a batch, against the oracle."""
+    import torch
+
+    from orbslam3_cpp_fork_amd import synth
+    from orbslam3_cpp_fork_amd._lib import KP_DTYPE
+    from orbslam3_cpp_fork_amd.extractor import ORBextractor
+
+    rows, cols = 376, 1241
+    frames = np.stack([synth.make_stereo_pair(rows, cols, camera_idx=i % 8, frame_idx=i // 8)[0] for i in (66, 67, 68)])
+    oex = oracle.OracleExtractor(2000, 1.2, 8, 20, 7)
+    ex = ORBextractor(2000)
+    ref = oex(frames[1], (0, 0))
+    assert_same_output(ref, ex(frames[1], None, (0, 0)), "sparse level, single frame")
+    cap = ex.max_keypoints(rows, cols)
+    k = torch.zeros((3, cap, 7), dtype=torch.float32, device="cuda")
+    ds = torch.zeros((3, cap, 32), dtype=torch.uint8, device="cuda")
+    c = torch.zeros((3, 2), dtype=torch.int32, device="cuda")
+    ex.extract_batch_device(torch.from_numpy(frames).cuda(), 3, rows, cols, cols, rows * cols, k, ds, c, cap, (0, 0))
+    torch.cuda.synchronize()
+    n = int(c[1, 0])
+    got = (int(c[1, 1]), k[1, :n].cpu().numpy().view(KP_DTYPE).reshape(-1), ds[1, :n].cpu().numpy())
+    assert_same_output(ref, got, "sparse level, inside a batch")
+    assert ex.debug_fault() is None
+    ex.close()
 
 
 def test_batch_device_matches_single(oracle, gpu_ex):

@@ -40,4 +40,5 @@ def test_extractor_parameter_sweep(oracle, case):
     for f in (0, 4, 8):
         assert cc[f, 0] == n and cc[f, 1] == rc0, (f, cc[f], n, rc0)
         assert (kk[f, :n] == k0.view(np.uint32).reshape(n, 7)).all() and (dd[f, :n] == d0).all(), "batch form, frame %d" % f
+    assert gex.debug_fault() is None  # no kernel met a count outside the capacity it indexes
     gex.close()

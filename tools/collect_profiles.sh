@@ -6,7 +6,7 @@
 #   (TCC_HIT_sum, TCC_MISS_sum: north_star's "L2 hit rate for the BRIEF pass"), and JSON summaries.
 # Usage: tools/collect_profiles.sh <tag>      -> gpurun_out/prof_<tag>/
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
@@ -24,4 +24,4 @@ timeout -k 10 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/calib -- python3 $R/tools/pmc_calibrate.py > $OUT/calib.log 2>&1 || echo "step failed (rc $?)"
 python3 $R/tools/valu_calibrate.py > $OUT/valu_calibration.json 2> $OUT/valu_calibration.err || echo "step failed (rc $?)"
 cd $R
-python3 tools/summarize_profiles.py $OUT > $OUT/summary.json && python3 tools/valu_summary.py $OUT > $OUT/valu_summary.json && cat $OUT/valu_summary.json
+python3 tools/summarize_profiles.py $OUT > $OUT/summary.json && python3 tools/valu_mix.py $OUT/valu_calibration.json > $OUT/valu_mix.json 2>/dev/null && python3 tools/valu_summary.py $OUT $OUT/valu_mix.json > $OUT/valu_summary.json && cat $OUT/valu_summary.json
