@@ -18,6 +18,7 @@ ranks (strong scaling); the stereo workload gives every rank its own pairs.  The
 records to rank 0.  Prints ONE JSON line (rank 0); `value` = units of all ranks / max-over-ranks wall time of the timed steps.
 """
 import argparse
+import gc
 import json
 import os
 import socket
@@ -297,6 +298,13 @@ def profile_summaries():
 
 
 # ------------------------------------------------------------------------------------------------------------------------------
+def quiesce_host():
+    """Before a timed region: collect now and keep the cycle collector out of the region (as timeit does).  A full collection with torch
+    loaded takes ~40 ms -- the host pass, which has three chunks (~4.5 ms of device work) in flight, drains completely behind one."""
+    gc.collect()
+    gc.disable()
+
+
 # stereo workload (config 4)
 # ------------------------------------------------------------------------------------------------------------------------------
 def run_stereo(args, c, rows, cols, nfeat):
@@ -360,6 +368,7 @@ def run_stereo(args, c, rows, cols, nfeat):
     trace("warm-up done")
     for ln in lanes:
         ln.gl.set_profiling(True)
+    quiesce_host()
     t0 = time.perf_counter()
     for i in range(args.steps):
         lanes[i % len(lanes)].step(timed=True)
@@ -367,6 +376,7 @@ def run_stereo(args, c, rows, cols, nfeat):
     fence(c)
     trace("timed steps done")
     dt = max_over_ranks(c, time.perf_counter() - t0)
+    gc.enable()
     # the stages with one chunk in flight (nothing beside them)
     ln = lanes[0]
     for x in lanes:
@@ -597,11 +607,13 @@ def main():
     stage_events = os.environ.get("ORBX_BENCH_NO_STAGE_EVENTS") is None  # A/B switch: what the HIP events between the stages cost the timed region
     for ln in lanes:
         ln.ex.set_profiling(stage_events)
+    quiesce_host()
     t0 = time.perf_counter()
     for i in range(args.steps):
         lanes[i % len(lanes)].step(timed=stage_events, chunk=nwarm + i)
     fence(c, lanes)
     dt = max_over_ranks(c, time.perf_counter() - t0)
+    gc.enable()
     if not stage_events:  # the stage figures then come from four more steps after the clock has stopped
         for ln in lanes:
             ln.ex.set_profiling(True)
@@ -667,11 +679,10 @@ def main():
 
         # four distinct chunks rotate (the stream and its three mirror images: other bytes, same statistics), so no step re-reads a
         # chunk an earlier step left in the caches
-        h_imgs = [pinned_array((B, rows, cols), np.uint8) for _ in range(4)]
-        h_imgs[0][:] = frames_np
-        h_imgs[1][:] = frames_np[:, ::-1, :]
-        h_imgs[2][:] = frames_np[:, :, ::-1]
-        h_imgs[3][:] = frames_np[:, ::-1, ::-1]
+        flips = (frames_np, frames_np[:, ::-1, :], frames_np[:, :, ::-1], frames_np[:, ::-1, ::-1])
+        h_imgs = [pinned_array((B, rows, cols), np.uint8) for _ in range(max(1, min(4, int(os.environ.get("ORBX_BENCH_HOST_CHUNKS", "4")))))]
+        for k, hbuf in enumerate(h_imgs):
+            hbuf[:] = flips[k]
         NH, depth = int(os.environ.get("ORBX_BENCH_HOST_HANDLES", "1")), int(os.environ.get("ORBX_BENCH_HOST_DEPTH", "3"))  # one handle, three chunks in flight: the path is bound by the H2D copies (two or three handles side by side, ORBX_BENCH_HOST_HANDLES, measured 157-161 k against 167 k frames/s)
 
         class HostLane:
@@ -720,12 +731,18 @@ def main():
             host_step(i)
         host_drain()
         fence(c)
+        quiesce_host()
         t0 = time.perf_counter()
+        stamps = []
         for i in range(args.steps):
             host_step(i)
+            stamps.append(time.perf_counter() - t0)
         host_drain()
         fence(c)
         dth = max_over_ranks(c, time.perf_counter() - t0)
+        gc.enable()
+        if os.environ.get("ORBX_BENCH_TRACE"):
+            print("bench.py[trace]: host pass, ms between submits: %s; total %.2f ms" % (" ".join("%.2f" % (1e3 * d) for d in np.diff([0.0] + stamps)), 1e3 * dth), file=sys.stderr, flush=True)
         in_b = B * rows * cols
         out_b = B * cap * 60 + B * 8 + (0 if args.no_match else B * cap * 4 + B * 4)
         pcie = {
