@@ -586,6 +586,9 @@ int orbx_extractor::makeGeometry(int rows, int cols) {
     } else {
       octLdsNodeCap = 0, octLdsBytes = fixed, octLdsPtsCap = 0;
     }
+#ifdef ORBX_TUNING
+    if (getenv("ORBX_OCT_NO_LDS")) octLdsNodeCap = 0, octLdsBytes = fixed, octLdsPtsCap = 0;  // experiment: the quadtree state in global memory
+#endif
   }
   geom     = g;
   haveGeom = true;

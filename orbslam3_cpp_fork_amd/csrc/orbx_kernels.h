@@ -545,13 +545,16 @@ __global__ __launch_bounds__(256) void k_layout(Bufs b, FrameGeom g, int lap0, i
   __shared__ int sCnt[kLayoutMaxRounds * 4 + 1];  // stereo keypoints per (round, wave), then their exclusive prefix
   const int      f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int*     lc = b.lvlCount + (long long)f * g.nlevels;
-  if (tid == 0) {
-    int n0 = 0;
-    for (int l = 0; l < g.nlevels; l++) {
-      sLbase[l] = n0;
-      n0 += checked_count(b.fault, kFaultLevelCount, f, l, lc[l], g.lv[l].kpCap);
+  if (wave == 0) {  // level bases: one lane per level loads its count (one memory round trip, not one per level), prefix by shuffles
+    const int c = lane < g.nlevels ? checked_count(b.fault, kFaultLevelCount, f, lane, lc[lane], g.lv[lane].kpCap) : 0;
+    int       inc = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int up = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += up;
     }
-    sLbase[g.nlevels] = n0;
+    if (lane < g.nlevels) sLbase[lane] = inc - c;
+    if (lane == g.nlevels - 1) sLbase[g.nlevels] = inc;
   }
   __syncthreads();
   const int       n      = sLbase[g.nlevels];
@@ -569,7 +572,32 @@ __global__ __launch_bounds__(256) void k_layout(Bufs b, FrameGeom g, int lap0, i
     rOut = r, lOut = l;
     return xs >= (float)lap0 && xs <= (float)lap1;
   };
-  for (int j = 0; j < rounds; j++) {
+  // The first kKeep rounds (2048 keypoints: every frame of the usual sizes) keep their record, level and flag in registers: their loads
+  // are all in flight at once, and the second pass does not load again.
+  constexpr int kKeep = 8;
+  uint32_t      rk[kKeep];
+  int           lk[kKeep];
+  unsigned      pk = 0;
+#pragma unroll
+  for (int j = 0; j < kKeep; j++) {
+    const int i = min(j * 256 + tid, max(n - 1, 0));
+    int       l = 0;
+    while (l + 1 < g.nlevels && i >= sLbase[l + 1]) l++;
+    lk[j] = l;
+    rk[j] = n > 0 ? kp[g.lv[l].kpBase + (i - sLbase[l])] : 0u;
+  }
+#pragma unroll
+  for (int j = 0; j < kKeep; j++) {
+    if (j < rounds) {
+      float xs = (float)(ot_cx(rk[j]) + kMinBorder);
+      if (lk[j] != 0) xs = xs * g.lv[lk[j]].scale;
+      const bool               p  = j * 256 + tid < n && xs >= (float)lap0 && xs <= (float)lap1;
+      const unsigned long long bm = __ballot(p);
+      pk |= (p ? 1u : 0u) << j;
+      if (lane == 0) sCnt[j * 4 + wave] = __popcll(bm);
+    }
+  }
+  for (int j = kKeep; j < rounds; j++) {
     const int                i  = j * 256 + tid;
     const unsigned long long bm = __ballot(i < n && pred(i));
     if (lane == 0) sCnt[j * 4 + wave] = __popcll(bm);
@@ -599,9 +627,7 @@ __global__ __launch_bounds__(256) void k_layout(Bufs b, FrameGeom g, int lap0, i
     if (lane == 63) sCnt[kLayoutMaxRounds * 4] = inc;  // total
   }
   __syncthreads();
-  for (int j = 0; j < rounds; j++) {
-    const int                i  = j * 256 + tid;
-    const bool               p  = i < n && pred(i);
+  auto emit = [&](int j, int i, bool p) {
     const unsigned long long bm = __ballot(p);
     if (i < n) {
       const int stereo = sCnt[j * 4 + wave] + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bm, 0u));
@@ -615,6 +641,17 @@ __global__ __launch_bounds__(256) void k_layout(Bufs b, FrameGeom g, int lap0, i
       oix[2 * i]     = make_int4((int)rOut, lOut | (row << 4), rawPitch, L.blurPitch);
       oix[2 * i + 1] = make_int4(rawOrg, blurOrg, __float_as_int(L.scale), L.patchSize);
     }
+  };
+#pragma unroll
+  for (int j = 0; j < kKeep; j++) {
+    if (j < rounds) {
+      rOut = rk[j], lOut = lk[j];
+      emit(j, j * 256 + tid, (pk >> j) & 1u);
+    }
+  }
+  for (int j = kKeep; j < rounds; j++) {
+    const int i = j * 256 + tid;
+    emit(j, i, i < n && pred(i));
   }
   if (tid == 0) {
     counts[2 * f]     = n;
