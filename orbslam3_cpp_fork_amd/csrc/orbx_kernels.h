@@ -676,6 +676,10 @@ __device__ __forceinline__ int reflect101(int p, int n) {
 // (4 bytes, one store) per input row.  No LDS, no second pass; neighbouring lanes' overlapping loads hit L1.
 // Work items are dealt level by level, 256 per workgroup (LevelGeom::blurTileBase counts workgroups).
 constexpr int kBlurRows = 16;  // rows per strip (32-row strips save the re-filtered halo rows but leave too few waves to hide the row loads: 0.19 -> 0.22 ms)
+#ifndef ORBX_BLUR_PREFETCH
+#define ORBX_BLUR_PREFETCH 3
+#endif
+constexpr int kBlurPrefetch = ORBX_BLUR_PREFETCH;  // rows of loads in flight ahead of the arithmetic
 constexpr int kBlurEdgeRows = 4;  // strip height of the edge items: few items, so short strips keep enough of them in flight
 
 // Three dwords covering columns x0-4 .. x0+7 of one row (reflect-101 at the image edges).
@@ -715,13 +719,23 @@ __device__ __forceinline__ void blur_strip(const uint8_t* __restrict__ src, int 
   const us2 W01 = {18, 34}, W23 = {48, 56}, W45 = {48, 34};
   uint32_t  pr[6][4];  // ring of packed row pairs, indexed with compile-time constants (the row loop is fully unrolled)
   uint32_t  hp[4] = {0, 0, 0, 0};
-#pragma unroll
-  for (int r = 0; r < ROWS + 6; r++) {
+  // Row loads run kBlurPrefetch rows ahead of the arithmetic (a ring of register slots, compile-time indices): the store of an output
+  // row sits in its own `oy < h` block, and a load placed behind that block cannot be moved above it by the compiler -- every row then
+  // paid one full memory round trip (load, s_waitcnt vmcnt(0), arithmetic, store).
+  constexpr int NS = kBlurPrefetch + 1;
+  uint32_t      la[NS], lm[NS], lc[NS];
+  auto          issue = [&](int r, int slot) {
     int sy = y0 + r - 3;  // reflect-101 rows; beyond the image bottom the strip's extra rows are never used
     sy     = sy < 0 ? -sy : sy;
     sy     = sy >= h ? max(2 * h - 2 - sy, 0) : sy;
-    uint32_t a, m, c;
-    blur_load12<FAST>(src + (long long)sy * pitch, x0, w, a, m, c);
+    blur_load12<FAST>(src + (long long)sy * pitch, x0, w, la[slot], lm[slot], lc[slot]);
+  };
+#pragma unroll
+  for (int r = 0; r < kBlurPrefetch; r++) issue(r, r % NS);
+#pragma unroll
+  for (int r = 0; r < ROWS + 6; r++) {
+    if (r + kBlurPrefetch < ROWS + 6) issue(r + kBlurPrefetch, (r + kBlurPrefetch) % NS);
+    const uint32_t a = la[r % NS], m = lm[r % NS], c = lc[r % NS];
     // horizontal pass: output column x0+i sees bytes (x0+i-3 .. x0+i+3); alignbyte slides the 12-byte window
     uint32_t hn[4];
     hn[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(c, m, 1), T1, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(m, a, 1), T0, 0u, false), false);
