@@ -149,6 +149,27 @@ def test_std_sort_reenactment_is_libstdcxx(oracle):
         assert (mine == oracle.std_sort(rec)).all(), (len(rec), rec[:8].tolist())
 
 
+def test_octree_host_model_sparse_levels(oracle):
+    """The same comparison where a level has barely more candidates than wanted corners (row-major feed, as the extractor feeds it)."""
+    from orbslam3_cpp_fork_amd.extractor import octree_host_model
+
+    rng = np.random.default_rng(4)
+    for trial in range(300):
+        W, H = int(rng.integers(300, 1300)), int(rng.integers(90, 400))
+        if round(np.float32(W) / np.float32(H)) < 1:
+            continue
+        N = int(rng.choice([17, 60, 123, 217, 434, 900]))
+        n = int(N * rng.uniform(0.5, 1.3))
+        px, py = rng.integers(3, W - 3, n), rng.integers(3, H - 3, n)
+        key = np.unique(py.astype(np.int64) * 4096 + px)
+        px, py = (key % 4096).astype(np.int32), (key // 4096).astype(np.int32)
+        rs = rng.integers(7, 60, len(px)).astype(np.int32)
+        n1, idx = oracle.distribute_octtree(px, py, rs, 16, 16 + W, 16, 16 + H, N)
+        rc, out = octree_host_model(px, py, rs, W, H, N)
+        exp = px[idx].astype(np.uint32) | (py[idx].astype(np.uint32) << 12) | (rs[idx].astype(np.uint32) << 24)
+        assert rc == 0 and len(out) == n1 and (out == exp).all(), (trial, W, H, len(px), N)
+
+
 def test_octree_depth_limit_case(oracle):
     """Level 0 of a KITTI-sized frame with 456 candidates for 434 wanted corners (golden fixture: the frame of the stereo bench the
     device quadtree once got wrong): its third ordered pass sorts 57 nodes whose keys run mostly downhill, and libstdc++'s introsort

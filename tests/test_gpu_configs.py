@@ -342,3 +342,44 @@ def test_full_chunk_matcher_properties(oracle):
     assert n.mean() > 300
     ex.close()
     mt.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["vga_stream", "stereo_left", "stereo_right"])
+def test_every_frame_of_the_bench_batches_equals_the_oracle(oracle, which):
+    """bench.py's own resident batches, frame by frame against the oracle (all 256 frames of the VGA stream, all 128 left and right
+    images of the stereo workload): data-dependent corner cases live in particular frames -- pair 67 of the stereo batch is the one whose
+    sparse level 0 drove the quadtree's sort into libstdc++'s depth limit."""
+    import torch
+
+    from orbslam3_cpp_fork_amd import synth
+    from orbslam3_cpp_fork_amd._lib import KP_DTYPE
+    from orbslam3_cpp_fork_amd.extractor import ORBextractor
+
+    if which == "vga_stream":
+        rows, cols, nf, lap = 480, 640, 1000, (0, 1000)
+        frames = synth.make_stream(rows, cols, 256)
+    else:
+        rows, cols, nf, lap = 376, 1241, 2000, (0, 0)
+        eye = 0 if which == "stereo_left" else 1
+        frames = np.stack([synth.make_stereo_pair(rows, cols, camera_idx=i % 8, frame_idx=i // 8)[eye] for i in range(128)])
+    B = len(frames)
+    ex = ORBextractor(nf)
+    cap = ex.max_keypoints(rows, cols)
+    k = torch.zeros((B, cap, 7), dtype=torch.float32, device="cuda")
+    ds = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
+    c = torch.zeros((B, 2), dtype=torch.int32, device="cuda")
+    ex.extract_batch_device(torch.from_numpy(frames).cuda(), B, rows, cols, cols, rows * cols, k, ds, c, cap, lap)
+    torch.cuda.synchronize()
+    assert ex.debug_fault() is None
+    cn, kn, dn = c.cpu().numpy(), k.cpu().numpy(), ds.cpu().numpy()
+    oex = oracle.OracleExtractor(nf, 1.2, 8, 20, 7)
+    for f in range(B):
+        mono, k0, d0 = oex(frames[f], lap)
+        n = int(cn[f, 0])
+        assert n == len(k0) and int(cn[f, 1]) == mono, (which, f, n, len(k0))
+        got = kn[f, :n].view(KP_DTYPE).reshape(-1)
+        for name in k0.dtype.names:
+            assert (got[name].view(np.uint32) == k0[name].view(np.uint32)).all(), (which, f, name)
+        assert (dn[f, :n] == d0).all(), (which, f)
+    ex.close()

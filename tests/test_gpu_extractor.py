@@ -113,6 +113,35 @@ def test_octree_device_random(oracle, gpu_ex):
         assert len(out) == n1 and (out == exp).all(), trial
 
 
+def test_octree_device_sparse_levels(oracle, gpu_ex):
+    """Levels with barely more candidates than wanted corners (n in [N / 2, 1.3 N]): many ordered passes, long runs of equal and
+    descending sort keys -- the regime of tests/golden/octree_depth_limit_case.npz, random this time."""
+    rng = np.random.default_rng(321)
+    checked = 0
+    for trial in range(60):
+        W, H = int(rng.integers(300, 1300)), int(rng.integers(90, 400))
+        if round(np.float32(W) / np.float32(H)) < 1:
+            continue
+        N = int(rng.choice([60, 123, 217, 434, 900]))
+        n = int(N * rng.uniform(0.5, 1.3))
+        if trial % 3 == 0:  # clustered: several points per node for a long time
+            cx, cy = rng.integers(20, W - 20, 12), rng.integers(10, H - 10, 12)
+            k = rng.integers(0, 12, n)
+            px = np.clip(cx[k] + rng.normal(0, W / 40, n), 3, W - 4).astype(int)
+            py = np.clip(cy[k] + rng.normal(0, H / 20, n), 3, H - 4).astype(int)
+        else:
+            px, py = rng.integers(3, W - 3, n), rng.integers(3, H - 3, n)
+        key = np.unique(py.astype(np.int64) * 4096 + px)  # feed order = row-major, as the extractor feeds it
+        px, py = (key % 4096).astype(np.int32), (key // 4096).astype(np.int32)
+        rs = rng.integers(7, 60, len(px)).astype(np.int32)
+        n1, idx = oracle.distribute_octtree(px, py, rs, 16, 16 + W, 16, 16 + H, N)
+        out = gpu_ex.debug_octree_device(px, py, rs, W, H, N)
+        exp = px[idx].astype(np.uint32) | (py[idx].astype(np.uint32) << 12) | (rs[idx].astype(np.uint32) << 24)
+        assert len(out) == n1 and (out == exp).all(), (trial, W, H, len(px), N)
+        checked += 1
+    assert checked > 40
+
+
 def test_wave_sort_is_std_sort(oracle, gpu_ex):
     """The wave-parallel std::sort re-enactment (ot_wave_sort) against the host build of the library algorithm (pinned against the real
     std::sort in tests/test_abi_and_hostmodel.py): every record in the same place, for tie-heavy, descending and median-of-3-hostile
