@@ -6,15 +6,16 @@ set -eu
 TAG=$1
 R=${2:-r03}
 P=gpurun_out/prof_$TAG
-cp $P/trace_default/runc/*_kernel_stats.csv profiles/${R}_default_kernel_stats.csv
-cp $P/trace/runc/*_kernel_stats.csv profiles/${R}_one_chunk_kernel_stats.csv
+newest() { ls -t $1 | head -1; }  # gpurun merges runs into the same scratch tree: an earlier run's files may lie beside the latest
+cp "$(newest ''$P'/trace_default/runc/*_kernel_stats.csv')" profiles/${R}_default_kernel_stats.csv
+cp "$(newest ''$P'/trace/runc/*_kernel_stats.csv')" profiles/${R}_one_chunk_kernel_stats.csv
 grep '^{"metric' $P/bench_trace_default.log | tail -1 > profiles/${R}_default_bench.json
 grep '^{"metric' $P/bench_trace.log | tail -1 > profiles/${R}_one_chunk_bench.json
-cp $P/pmc_fetch/runc/*_counter_collection.csv profiles/${R}_pmc_fetch_size.csv
-cp $P/pmc_write/runc/*_counter_collection.csv profiles/${R}_pmc_write_size.csv
-cp $P/pmc_sq/runc/*_counter_collection.csv profiles/${R}_pmc_sq.csv
-cp $P/pmc_tcc/runc/*_counter_collection.csv profiles/${R}_pmc_tcc_hit_miss.csv
-cp $P/calib/runc/*_counter_collection.csv profiles/${R}_pmc_calibration.csv
+cp "$(newest ''$P'/pmc_fetch/runc/*_counter_collection.csv')" profiles/${R}_pmc_fetch_size.csv
+cp "$(newest ''$P'/pmc_write/runc/*_counter_collection.csv')" profiles/${R}_pmc_write_size.csv
+cp "$(newest ''$P'/pmc_sq/runc/*_counter_collection.csv')" profiles/${R}_pmc_sq.csv
+cp "$(newest ''$P'/pmc_tcc/runc/*_counter_collection.csv')" profiles/${R}_pmc_tcc_hit_miss.csv
+cp "$(newest ''$P'/calib/runc/*_counter_collection.csv')" profiles/${R}_pmc_calibration.csv
 cp $P/valu_calibration.json profiles/${R}_valu_calibration.json
 cp $P/summary.json profiles/${R}_pmc_summary.json
 python3 tools/valu_mix.py profiles/${R}_valu_calibration.json > profiles/${R}_valu_mix.json 2>/dev/null
