@@ -87,7 +87,8 @@ struct OtArgs {
   int*      outCount;
   long long* dbgT;  // optional diagnostic stamps (device tuning builds): [0] sort cycles, [1] total cycles, [2] division steps, [3] sorts,
                     // [4] cycles in the passes over the points, [5] per-node scans, [6] node rewrite, [7] root set-up
-  unsigned long long* dbgSort;  // optional (orbx_debug_octree_sorts): [0] = sorts so far; per sort 1 + 2 * 256 words: V, records before, records after
+  unsigned long long* dbgSort;  // optional (orbx_debug_octree_sorts): [0] = sorts on record; per sort 1 + 2 * 256 words: V, records before, records after
+  int                 dbgSortCap;  // sorts the buffer holds (later ones are not recorded)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -824,7 +825,8 @@ OT_HD inline void ot_distribute(CTX& c, const OtArgs& a) {
                          (unsigned long long)(unsigned)j;
         }
         c.sync();
-        if (a.dbgSort && V <= 256) {
+        const bool recordSort = a.dbgSort && V <= 256 && (int)a.dbgSort[0] < a.dbgSortCap;
+        if (recordSort) {
           unsigned long long* d = a.dbgSort + 1 + a.dbgSort[0] * 513;
           if (c.tid == 0) d[0] = (unsigned long long)V;
           for (int j = c.tid; j < V; j += c.nt) d[1 + j] = a.sortbuf[j];
@@ -833,7 +835,7 @@ OT_HD inline void ot_distribute(CTX& c, const OtArgs& a) {
         const long long t0 = OT_CLOCK();
         c.sort(a.sortbuf, V);
         c.sync();
-        if (a.dbgSort && V <= 256) {
+        if (recordSort) {
           unsigned long long* d = a.dbgSort + 1 + a.dbgSort[0] * 513;
           for (int j = c.tid; j < V; j += c.nt) d[257 + j] = a.sortbuf[j];
           c.sync();

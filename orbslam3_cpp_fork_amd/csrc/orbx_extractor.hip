@@ -1505,7 +1505,7 @@ int orbx_debug_octree_sorts(orbx_t* h, const uint32_t* cand, int n, int W, int H
   DevBuf<Int4>               sc;
   DevBuf<Idx4>               ec;
   DevBuf<unsigned long long> sb, bst, dsort;
-  const size_t               sortWords = sorts ? 1 + (size_t)max_sorts * 513 + 513 : 0;
+  const size_t               sortWords = sorts ? 1 + (size_t)max_sorts * 513 : 0;
   if (sorts && (dsort.ensure(sortWords) || hipMemset(dsort.p, 0, sortWords * 8) != hipSuccess)) return -3;
   if (dc.ensure(np) || dout.ensure(nn) || nA.ensure(np) || bst.ensure(nn) ||
       nodesA.ensure(nn) || nodesB.ensure(nn) || sc.ensure(nn) || ec.ensure(nn) || D.ensure(nn) || dI.ensure(nn) ||
@@ -1519,7 +1519,7 @@ int orbx_debug_octree_sorts(orbx_t* h, const uint32_t* cand, int n, int W, int H
   a.nodeOf = nA.p, a.best = bst.p, a.nodesA = nodesA.p, a.nodesB = nodesB.p;
   a.childCnt = sc.p, a.childIdx = ec.p, a.D = D.p, a.dIndex = dI.p, a.nCh = nCh.p, a.pushOff = pO.p, a.multiOff = mO.p, a.keptRank = kR.p;
   a.vA = vA.p, a.vB = vB.p, a.sortbuf = sb.p, a.outKp = dout.p, a.outCount = cnt.p;
-  a.dbgSort = sorts ? dsort.p : nullptr;
+  a.dbgSort = sorts ? dsort.p : nullptr, a.dbgSortCap = max_sorts;
   hipLaunchKernelGGL(k_octree_only, dim3(1), dim3(kOctThreads), 0, h->stream, a);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(h->stream));
