@@ -20,3 +20,13 @@ def test_repeated_steps_give_identical_bytes(shape):
                        timeout=600)
     assert p.returncode == 0, (p.stdout[-3000:], p.stderr[-2000:])
     assert "differing" not in p.stdout and "count fault" not in p.stdout and "done" in p.stdout, p.stdout[-3000:]
+
+
+def test_repeated_mono_steps_with_the_matcher_give_identical_bytes():
+    """bench.py's default step (extract 256 VGA frames, brute-force match of consecutive frames with greedy claims in speculative rounds)
+    on three lanes: keypoints, descriptors, counts, match lists and match counts of every step equal the first step's."""
+    env = dict(os.environ, MODE="mono")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_determinism.py"), "24", "12", "480", "640", "1000", "256"], capture_output=True, text=True, timeout=600,
+                       env=env)
+    assert p.returncode == 0, (p.stdout[-3000:], p.stderr[-2000:])
+    assert "differing" not in p.stdout and "count fault" not in p.stdout and "done" in p.stdout, p.stdout[-3000:]

@@ -2,7 +2,9 @@
 the bench has them) runs the SAME batch every step, and every step's outputs are compared on the device with the first step's.  Any
 difference is a race (the path is deterministic by contract); the report names the output, the step and the frames.
 
-usage: check_determinism.py [steps] [sync_every] [rows cols nfeatures B]"""
+usage: check_determinism.py [steps] [sync_every] [rows cols nfeatures B]
+MODE=mono: bench.py's default step instead -- one extractor per lane on the synthetic stream and the brute-force matcher on consecutive
+frames (match lists and counts compared as well)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import numpy as np, torch
@@ -12,8 +14,70 @@ steps = int(sys.argv[1]) if len(sys.argv) > 1 else 180
 SYNC_EVERY = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 rows, cols, nf, B = (int(x) for x in sys.argv[3:7]) if len(sys.argv) > 6 else (376, 1241, 2000, 128)
 NL = int(os.environ.get("LANES", "3"))
+MONO = os.environ.get("MODE") == "mono"
 STEREO = os.environ.get("NO_STEREO") != "1"
 PROFILING = os.environ.get("NO_PROFILING") != "1"
+if MONO:
+    from orbslam3_cpp_fork_amd.matcher import ORBmatcher
+    frames = synth.make_stream(rows, cols, B)
+    dF = torch.from_numpy(frames).cuda()
+    d_pairs = torch.from_numpy(np.stack([(np.arange(B) - 1) % B, np.arange(B)], 1).astype(np.int32)).cuda()
+    mlanes = []
+    for li in range(NL):
+        ex, mt = ORBextractor(nf), ORBmatcher(0.7, True)
+        cap = ex.max_keypoints(rows, cols)
+        t = dict(k=torch.zeros((B, cap, 7), dtype=torch.float32, device="cuda"), d=torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda"),
+                 c=torch.zeros((B, 2), dtype=torch.int32, device="cuda"), m=torch.full((B, cap), -1, dtype=torch.int32, device="cuda"), nm=torch.zeros(B, dtype=torch.int32, device="cuda"))
+        st = _lib.lib().orbx_stream_create(0)
+        mlanes.append(dict(ex=ex, mt=mt, t=t, st=st, ts=torch.cuda.ExternalStream(st), cap=cap, ref=None, bad={k: torch.zeros(B, dtype=torch.int32, device="cuda") for k in t}))
+    def mstep(ln):
+        t, st, cap = ln["t"], ln["st"], ln["cap"]
+        with torch.cuda.stream(ln["ts"]):
+            ln["ex"].extract_batch_device(dF, B, rows, cols, cols, rows * cols, t["k"], t["d"], t["c"], cap, (0, 1000), stream=st)
+            ln["mt"].match_pairs_device(t["d"], t["k"], t["c"], cap, d_pairs, B, t["m"], t["nm"], stream=st)
+            if ln["ref"] is None:
+                ln["ref"] = {k: v.clone() for k, v in t.items()}
+                return
+            ref = ln["ref"]
+            valid = torch.arange(cap, device="cuda")[None, :] < ref["c"][:, 0:1]
+            qvalid = valid[d_pairs[:, 0].long()]  # match lists are indexed by the query frame's features
+            for k in t:
+                a, b = t[k], ref[k]
+                if k in ("k", "d"):
+                    d = ((a.view(torch.int32) if a.dtype == torch.float32 else a) != (b.view(torch.int32) if b.dtype == torch.float32 else b)).any(dim=2)
+                    d = (d & valid).sum(dim=1)
+                elif k == "m":
+                    d = ((a != b) & qvalid).sum(dim=1)
+                elif k == "nm":
+                    d = (a != b).int()
+                else:
+                    d = (a != b).any(dim=1).int()
+                ln["bad"][k] += d.int()
+    def mreport(i):
+        torch.cuda.synchronize()
+        msgs = []
+        for li, ln in enumerate(mlanes):
+            for k in ln["t"]:
+                b = ln["bad"][k].cpu().numpy()
+                if b.any():
+                    msgs.append("lane%d.%s: %d differing records over frames %s" % (li, k, int(b.sum()), np.nonzero(b)[0][:12].tolist()))
+            f = ln["ex"].debug_fault()
+            if f:
+                msgs.append("lane%d count fault %s" % (li, f))
+        print("step %d: %s" % (i, "; ".join(msgs) if msgs else "all outputs identical to the first step's"), flush=True)
+        return bool(msgs)
+    for ln in mlanes:
+        mstep(ln)
+    torch.cuda.synchronize()
+    bad = False
+    for i in range(steps):
+        mstep(mlanes[i % NL])
+        if i % SYNC_EVERY == SYNC_EVERY - 1 and mreport(i + 1):
+            bad = True
+            break
+    bad = mreport(steps) or bad
+    print("done", flush=True)
+    sys.exit(1 if bad else 0)
 pairs = [synth.make_stereo_pair(rows, cols, camera_idx=i % 8, frame_idx=i // 8) for i in range(B)]
 dL = torch.from_numpy(np.stack([p[0] for p in pairs])).cuda(); dR = torch.from_numpy(np.stack([p[1] for p in pairs])).cuda()
 z = lambda shape, dt: torch.zeros(shape, dtype=dt, device="cuda")
