@@ -342,8 +342,8 @@ int orbx_extractor::makeGeometry(int rows, int cols) {
     LevelGeom& L = g.lv[l];
     L.w = cvRoundF((float)cols * invSf[l]);  // src/ORBextractor.cc:1142-1143
     L.h = cvRoundF((float)rows * invSf[l]);
-    if (L.w < 8 || L.h < 8) {
-      g_err = "image too small for the pyramid depth: a level is narrower than 8 px";
+    if (L.w < 1 || L.h < 1 || (l == 0 && (L.w < 8 || L.h < 8))) {  // cv::resize asserts on an empty destination; levels of 1 .. 7 px are produced (k_resize_tiny)
+      g_err = "image too small for the pyramid depth: a level would be empty (or the image itself is smaller than 8 x 8)";
       return -2;
     }
     L.pitch = alignUp(L.w, 64);
@@ -412,7 +412,7 @@ int orbx_extractor::makeGeometry(int rows, int cols) {
     L.patchSize = (int)(kPatchSize * sf[l]);  // src/ORBextractor.cc:865
     // blur tiles
     L.blurTilesX   = (L.w + 3) / 4;                          // 4-column groups
-    L.blurTilesY   = (L.h + kBlurRows - 1) / kBlurRows;      // row strips
+    L.blurTilesY   = level_is_tiny(L) ? 0 : (L.h + kBlurRows - 1) / kBlurRows;  // row strips (a tiny level is not blurred: no keypoint can lie on it)
     {
       // interior groups (12-byte window inside the row) go to k_blur_levels, the 2-3 edge groups of every strip to
       // k_blur_edges; an unaligned level 0 sends ALL its groups to the edge kernel, so that grid is sized for it
@@ -598,6 +598,7 @@ int orbx_extractor::makeGeometry(int rows, int cols) {
   // tables, produces every level for batches as well
   pyrBandsOnly = false;
   for (int l = 1; l < g.nlevels; l++) {
+    if (level_is_tiny(g.lv[l])) continue;  // k_resize_tiny
     const double sx = (double)g.lv[l - 1].w / g.lv[l].w, sy = (double)g.lv[l - 1].h / g.lv[l].h;
     if (sx * kRsTileW + 6 > kRsLdsW || sy * (kRsTileH - 1) + 3 > kRsLdsH - 1) pyrBandsOnly = true;
   }
@@ -605,8 +606,11 @@ int orbx_extractor::makeGeometry(int rows, int cols) {
   hYtab = yt;
   pyrLatency[0].valid = pyrLatency[1].valid = false;
   if (g.nlevels > 1) {
-    const int mid = std::min((g.nlevels + 1) / 2, g.nlevels - 1);
-    const int ends[3] = {1, g.nlevels > 2 ? mid : g.nlevels, g.nlevels};
+    int chainEnd = g.nlevels;  // the band kernel takes the levels before the first tiny one
+    for (int l = g.nlevels - 1; l >= 1; l--)
+      if (level_is_tiny(g.lv[l])) chainEnd = l;
+    const int mid = std::min((chainEnd + 1) / 2, chainEnd - 1);
+    const int ends[3] = {1, chainEnd > 2 ? std::max(mid, 1) : chainEnd, chainEnd};
     int       rc2 = 0;
     for (int part = 0; part < 2; part++) {
       if (ends[part] >= ends[part + 1]) continue;
@@ -743,6 +747,11 @@ int orbx_extractor::run(const uint8_t* d_imgs, int B, int rows, int cols, size_t
       int part = -1;
       for (int q = 0; q < 2; q++)
         if (covered[q][0] == l && covered[q][1] > l) part = q;
+      if (level_is_tiny(g.lv[l])) {
+        hipLaunchKernelGGL(k_resize_tiny, dim3(B), dim3(256), 0, s, b, g, l);
+        l++;
+        continue;
+      }
       if (part < 0) {
         if (pyrBandsOnly) {
           g_err = "scale factor above ~1.3 on an image this wide: the pyramid band kernel's LDS plan does not fit";
@@ -1453,6 +1462,10 @@ int orbx_debug_blurred_level(orbx_t* h, int frame, int level, uint8_t* dst, size
   if (!h || !h->haveGeom || level < 0 || level >= h->nlevels || frame < 0 || frame >= h->lastB) return -2;
   HIP_TRY(hipSetDevice(h->device));
   const orbx::LevelGeom& L = h->geom.lv[level];
+  if (orbx::level_is_tiny(L)) {
+    g_err = "orbx_debug_blurred_level: levels below 8 x 8 px are not blurred (no keypoint can lie on them)";
+    return -2;
+  }
   return copy_level(h, h->bufs.blur + (long long)frame * h->geom.blurBytes + L.blurOff, L.blurPitch, L.w, L.h, dst, dst_step, rows, cols);
 }
 

@@ -204,6 +204,31 @@ __global__ __launch_bounds__(256) void k_resize_level(Bufs b, FrameGeom g, int l
                      blockIdx.x >> 3, blockIdx.y);
 }
 
+// A level narrower or lower than 8 px (deep pyramids of small or very elongated images: 1077 x 137 at scale 1.5 has a 42 x 5 level 8).
+// It is far too small for a FAST cell, so nothing downstream reads it except the next level of the chain and the public pyramid
+// accessor; the tiled kernels (4-px groups, single reflection at the borders) do not take it.  One thread per pixel, the same tables
+// and the same arithmetic as resize_tile; such a level is not blurred (no keypoint can lie on it).
+__host__ __device__ inline bool level_is_tiny(const LevelGeom& L) { return L.w < 8 || L.h < 8; }
+
+__global__ __launch_bounds__(256) void k_resize_tiny(Bufs b, FrameGeom g, int level) {
+  const int        f  = blockIdx.x;
+  const LevelGeom& L  = g.lv[level];
+  const LevelGeom& Ls = g.lv[level - 1];
+  int              sp;
+  const uint8_t*   S = level_raw(b, g, level - 1, f, &sp);
+  uint8_t*         D = b.pyr + (long long)f * g.pyrBytes + L.pyrOff;
+  const int2 *     xtab = b.xtab + L.xtabOff, *ytab = b.ytab + L.ytabOff;
+  for (int i = threadIdx.x; i < L.w * L.h; i += 256) {
+    const int  dy = i / L.w, dx = i - dy * L.w;
+    const int2 xt = xtab[dx], yt = ytab[dy];
+    const int  c = xt.x, c1 = min(c + 1, Ls.w - 1), a0 = (short)(xt.y & 0xffff), a1 = xt.y >> 16;
+    const int  r0 = min(max(yt.x, 0), Ls.h - 1), r1 = min(max(yt.x + 1, 0), Ls.h - 1), b0 = (short)(yt.y & 0xffff), b1 = yt.y >> 16;
+    const int  h0 = S[(long long)r0 * sp + c] * a0 + S[(long long)r0 * sp + c1] * a1;
+    const int  h1 = S[(long long)r1 * sp + c] * a0 + S[(long long)r1 * sp + c1] * a1;
+    D[dy * L.pitch + dx] = (uint8_t)((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // ComputePyramid, several levels in ONE launch -- the latency form of the chain (src/ORBextractor.cc:1140-1173: each level is resized from
 // the previous one, so the chain itself cannot go, but for a handful of frames it need not be a chain of seven launches, each of which
@@ -799,7 +824,7 @@ __global__ __launch_bounds__(256, 8) void k_blur_levels(Bufs b, FrameGeom g, int
 constexpr int kBlurEdgeOutRows = 250;  // output rows per workgroup (256 input rows with the 3 + 3 halo)
 constexpr int kBlurEdgeCols    = 12;   // 4 left + up to 8 right
 
-__host__ __device__ inline int blur_edge_blocks(const LevelGeom& L) { return (L.h + kBlurEdgeOutRows - 1) / kBlurEdgeOutRows; }
+__host__ __device__ inline int blur_edge_blocks(const LevelGeom& L) { return level_is_tiny(L) ? 0 : (L.h + kBlurEdgeOutRows - 1) / kBlurEdgeOutRows; }
 
 __device__ __forceinline__ void blur_edges_block(const Bufs& b, const FrameGeom& g, int firstLevel, int block, int f) {
   __shared__ uint32_t hs[256][kBlurEdgeCols + 1];

@@ -33,6 +33,9 @@ CASES = [
     ((479, 637), 1000, 1.2, 8, 20, 7, (0, 1000), True),
     ((3000, 4000), 5000, 1.2, 8, 20, 7, (0, 0), False),
     ((2000, 3000), 2000, 1.5, 6, 20, 7, (0, 1000), False),
+    # levels of a few pixels (deep pyramid of an elongated / small image): no keypoints there, but the chain and the pyramid accessor go on
+    ((137, 1077), 2000, 1.5, 9, 7, 7, (0, 0), False),
+    ((90, 120), 300, 1.3, 10, 20, 7, (0, 0), False),
 ]
 
 

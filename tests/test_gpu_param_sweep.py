@@ -27,6 +27,10 @@ def test_extractor_parameter_sweep(oracle, case):
     rc, k, d = gex(img, None, lap)
     assert rc == rc0 and len(k) == len(k0), (rc, rc0, len(k), len(k0))
     assert (k.view(np.uint32) == k0.view(np.uint32)).all() and (d == d0).all()
+    oex = oracle.OracleExtractor(nf, sf, nl, ini, mn)
+    oex(img, lap)
+    for l in range(nl):  # the public pyramid (mvImagePyramid), levels of a few pixels included
+        assert (gex.pyramid_level(l) == oex.pyramid_level(l)).all(), "pyramid level %d" % l
     if h * w > 1300 * 1700:
         return
     B, cap, n = 9, gex.max_keypoints(h, w), len(k0)
@@ -42,3 +46,16 @@ def test_extractor_parameter_sweep(oracle, case):
         assert (kk[f, :n] == k0.view(np.uint32).reshape(n, 7)).all() and (dd[f, :n] == d0).all(), "batch form, frame %d" % f
     assert gex.debug_fault() is None  # no kernel met a count outside the capacity it indexes
     gex.close()
+
+
+@pytest.mark.gpu
+def test_fuzz_parity_campaign():
+    """tools/fuzz_parity.py, 120 cases: images of very different statistics (flat with dots, noise, smoothed noise, gradients,
+    checkerboards, saturated blobs, texture at the thresholds, the bench worlds) x sizes x constructor parameters, single call and batch."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "120", "7"], capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0 and "all equal" in p.stdout and "MISMATCH" not in p.stdout, (p.stdout[-2000:], p.stderr[-1500:])
