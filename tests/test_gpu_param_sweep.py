@@ -59,3 +59,17 @@ def test_fuzz_parity_campaign():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     p = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "120", "7"], capture_output=True, text=True, timeout=900)
     assert p.returncode == 0 and "all equal" in p.stdout and "MISMATCH" not in p.stdout, (p.stdout[-2000:], p.stderr[-1500:])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tool,args", [("fuzz_stereo.py", ["40", "5"]), ("fuzz_matcher.py", ["150", "5"])])
+def test_fuzz_campaigns_of_the_next_rows(tool, args):
+    """tools/fuzz_stereo.py (ComputeStereoMatches on random image pairs with layered disparities) and tools/fuzz_matcher.py (the
+    brute-force SearchByBoW pass on tie-heavy descriptor sets), short runs; the long runs are on record in DESIGN.md."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", tool)] + args, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0 and "all equal" in p.stdout and "MISMATCH" not in p.stdout, (p.stdout[-2000:], p.stderr[-1500:])
