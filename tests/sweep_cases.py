@@ -46,6 +46,9 @@ def sweep_image(h, w, strided):
     H, W = h + (20 if strided else 0), w + (60 if strided else 0)
     if H >= 240 and W >= 320:
         img = synth.make_frame(H, W, 3, (h * 7 + w) % 23)
-    else:
+    elif H <= 380 and W <= 490:
         img = synth.make_frame(480, 640, 3, (h * 7 + w) % 23)[100:100 + H, 150:150 + W].copy()
+    else:  # small in one direction only
+        img = synth.make_frame(max(H, 240), max(W, 320), 3, (h * 7 + w) % 23)[:H, :W].copy()
+    assert img.shape == (H, W)
     return img[10:10 + h, 30:30 + w] if strided else img

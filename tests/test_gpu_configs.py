@@ -205,15 +205,18 @@ def test_undistort_keypoints_device(oracle):
         assert u.tobytes() == oracle.undistort_keypoints(k, K, dist).tobytes()
 
 
-def test_stereo_matches_batch_device(oracle):
-    """N1, device-batch form: ComputeStereoMatches for every pair of two extraction batches (config 4: two handles per step)."""
+@pytest.mark.parametrize("which", ["three_pairs", "bench_batch"])
+def test_stereo_matches_batch_device(oracle, which):
+    """N1, device-batch form: ComputeStereoMatches for every pair of two extraction batches (config 4: two handles per step) -- three pairs,
+    and all 128 pairs of bench.py's stereo workload (uRight and depth of every left keypoint as float bits)."""
     import torch
 
     from orbslam3_cpp_fork_amd import _lib, synth
     from orbslam3_cpp_fork_amd.extractor import ORBextractor
 
-    B, (h, w), nf = 3, (376, 1241), 2000
-    pairs = [synth.make_stereo_pair(h, w, camera_idx=5 + i) for i in range(B)]
+    B, (h, w), nf = (3 if which == "three_pairs" else 128), (376, 1241), 2000
+    pairs = [synth.make_stereo_pair(h, w, camera_idx=5 + i) for i in range(B)] if which == "three_pairs" else [
+        synth.make_stereo_pair(h, w, camera_idx=i % 8, frame_idx=i // 8) for i in range(B)]
     L = np.stack([p[0] for p in pairs])
     R = np.stack([p[1] for p in pairs])
     gl, gr = ORBextractor(nf), ORBextractor(nf)
@@ -241,7 +244,7 @@ def test_stereo_matches_batch_device(oracle):
         _, okr, odr = orr(R[f], (0, 0))
         n0, u0, d0 = oracle.stereo_matches(ol, orr, okl, odl, okr, odr, mb, mbf)
         nl = int(cl[f, 0])
-        assert nl == len(okl) and int(kept[f]) == n0 and n0 > 50
+        assert nl == len(okl) and int(kept[f]) == n0 and n0 > 30, (f, nl, len(okl), int(kept[f]), n0)
         assert (ur[f, :nl].cpu().numpy().view(np.uint32) == u0.view(np.uint32)).all()
         assert (dp[f, :nl].cpu().numpy().view(np.uint32) == d0.view(np.uint32)).all()
 
