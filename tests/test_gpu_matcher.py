@@ -1,8 +1,13 @@
 """GPU parity tests of the Hamming matcher (orbm_*) vs the CPU oracle."""
+import os
+
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+
+# ORBX_TEST_SEED_FACTOR=25 turns the random-scene tests below into a long campaign (25 x their usual number of scenes)
+SEED_FACTOR = int(os.environ.get("ORBX_TEST_SEED_FACTOR", "1"))
 
 
 @pytest.fixture(scope="module")
@@ -294,7 +299,7 @@ def test_projection_searches_random_scenes(oracle):
 
     sf = (np.float32(1.2) ** np.arange(8)).astype(np.float32)
     bounds = (0.0, 640.0, 0.0, 480.0)
-    for seed in range(24):
+    for seed in range(24 * SEED_FACTOR):
         rng = np.random.default_rng(1000 + seed)
         n1, n2 = int(rng.integers(40, 500)), int(rng.integers(40, 500))
         ncl = int(rng.integers(3, 30))
@@ -341,7 +346,7 @@ def test_windowed_searches_random_scenes(oracle):
     bounds = (-12.5, 651.0, -9.0, 489.5)
     m = ORBmatcher(0.75, True)
     totals = [0, 0, 0, 0]
-    for seed in range(16):
+    for seed in range(16 * SEED_FACTOR):
         rng = np.random.default_rng(7000 + seed)
         n1, n2 = int(rng.integers(30, 600)), int(rng.integers(30, 600))
         ncl = int(rng.integers(3, 30))
@@ -432,7 +437,7 @@ def test_search_for_triangulation(oracle):
     K = np.array([[460.0, 0, 320.0], [0, 455.0, 240.0], [0, 0, 1]])
     Ki = np.linalg.inv(K)
     total = 0
-    for seed in range(16):
+    for seed in range(16 * SEED_FACTOR):
         rng = np.random.default_rng(9100 + seed)
         n1, n2 = int(rng.integers(1, 900)), int(rng.integers(1, 900))
         # small rotation + translation mostly along x: epipolar lines are close to the rows
@@ -558,7 +563,7 @@ def test_search_by_projection_map_two_cameras(oracle):
     sf = (np.float32(1.2) ** np.arange(8)).astype(np.float32)
     bounds = (0.0, 640.0, 0.0, 480.0)
     total = vetoes = 0
-    for seed in range(20):
+    for seed in range(20 * SEED_FACTOR):
         rng = np.random.default_rng(2000 + seed)
         n1, nleft, nright = int(rng.integers(40, 600)), int(rng.integers(30, 500)), int(rng.integers(30, 500))
         n = nleft + nright
