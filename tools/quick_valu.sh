@@ -7,8 +7,8 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/qv_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU --output-format csv -d $OUT/pmc -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-pcie --lanes 1 > $OUT/bench_pmc.log 2>&1 || echo "step failed (rc $?)"
-[ -n "${QUICK_VALU_NO_TRACE:-}" ] || timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --no-cpu-baseline --no-pcie --lanes 1 > $OUT/bench.log 2>&1 || echo "step failed (rc $?)"
+timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU --output-format csv -d $OUT/pmc -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-pcie --no-single-call --lanes 1 > $OUT/bench_pmc.log 2>&1 || echo "step failed (rc $?)"
+[ -n "${QUICK_VALU_NO_TRACE:-}" ] || timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --no-cpu-baseline --no-pcie --no-single-call --lanes 1 > $OUT/bench.log 2>&1 || echo "step failed (rc $?)"
 cd $R
 python3 - "$OUT" <<'PY'
 import collections, csv, glob, re, sys
