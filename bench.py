@@ -429,8 +429,8 @@ def run_stereo(args, c, rows, cols, nfeat):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=60, help="timed steps (60 x 256 frames = 15 360 frames, ~60 ms: long enough for the clocks to settle; 20 gave +-3 %% run to run)")
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200, help="timed steps (200 x 256 frames = 51 200 frames, ~0.2 s: 60 steps still read 1-3 %% below 200 / 600 on the same box, 20 gave +-3 %% run to run)")
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--frames", type=int, default=256, help="frames per step and per GPU, resident in HBM (rig workload: per step over ALL GPUs, 8 cameras x frames/8)")
     ap.add_argument("--workload", default="vga_stream_640x480_8lvl_1000feat_extract+match", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
