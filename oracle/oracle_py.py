@@ -136,11 +136,15 @@ class OracleExtractor:
         if image is None or image.size == 0:
             return -1, np.zeros(0, KP_DTYPE), np.zeros((0, 32), np.uint8)
         img = _u8img(image)
-        cap = cap or (self.nfeatures + 8 * self.nlevels + 64) * 2
-        kps = np.zeros(cap, KP_DTYPE)
-        desc = np.zeros((cap, 32), np.uint8)
-        n = C.c_int(0)
-        rc = lib().orao_extract(self._h, _p(img), img.shape[0], img.shape[1], img.strides[0], lapping[0], lapping[1], _p(kps), _p(desc), cap, C.byref(n))
+        # -2 is also what a too small record capacity returns: a very elongated image with a small quota starts every level with
+        # round(width / height) root nodes and divides each of them once (up to 4 x roots keypoints per level), far more than nfeatures
+        for c in ([cap] if cap else [(self.nfeatures + 8 * self.nlevels + 64) * 2, 65536]):
+            kps = np.zeros(c, KP_DTYPE)
+            desc = np.zeros((c, 32), np.uint8)
+            n = C.c_int(0)
+            rc = lib().orao_extract(self._h, _p(img), img.shape[0], img.shape[1], img.strides[0], lapping[0], lapping[1], _p(kps), _p(desc), c, C.byref(n))
+            if rc != -2:
+                break
         return rc, kps[: n.value].copy(), desc[: n.value].copy()
 
     def scale_tables(self):

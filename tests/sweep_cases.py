@@ -36,6 +36,9 @@ CASES = [
     # levels of a few pixels (deep pyramid of an elongated / small image): no keypoints there, but the chain and the pyramid accessor go on
     ((137, 1077), 2000, 1.5, 9, 7, 7, (0, 0), False),
     ((90, 120), 300, 1.3, 10, 20, 7, (0, 0), False),
+    # an elongated image with a tiny quota: every level starts with round(width / height) roots and divides each once -- several times
+    # nfeatures keypoints come out (the record capacity is orbx_max_keypoints, not nfeatures)
+    ((126, 961), 20, 1.1, 8, 5, 20, (0, 1000), False),
 ]
 
 
