@@ -494,7 +494,7 @@ def main():
     # bytes, same statistics, consecutive frames still match): 4 x 78.6 MB of level-0 input at VGA is more than the 256 MiB Infinity
     # Cache, so no step finds the frames it reads left behind by the step before.
     d_chunks = [d_imgs, d_imgs.flip(1).contiguous(), d_imgs.flip(2).contiguous(), d_imgs.flip(1, 2).contiguous()]
-    NCH = len(d_chunks)
+    NCH = max(1, min(len(d_chunks), int(os.environ.get("ORBX_BENCH_CHUNKS", "4"))))  # ORBX_BENCH_CHUNKS=2: round 2's protocol (two chunks alternating), for like-for-like comparisons
 
     voc = None
     if args.bow and not args.no_match:
